@@ -1,0 +1,212 @@
+/* tethys_mi.h — C ABI of libtethys_mi.so: the MI355X (gfx950) kernels behind the
+ * tethys-speech data-parallel training step.
+ *
+ * The reference (hyunnnchoi/tethys-speech) has NO plugin / FFI interface: its hot path is
+ * stock TensorFlow ops called from speech_jobs/whisper_dist.py and
+ * speech_jobs/wav2vec2_dist.py.  Each entry point below therefore cites the
+ * TensorFlow call site(s) in those files whose device arithmetic it replaces
+ * ("W:" = speech_jobs/whisper_dist.py, "V:" = speech_jobs/wav2vec2_dist.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it;
+ *   - no allocation, no synchronisation, no hidden state inside any call: the caller owns
+ *     every buffer including workspaces (sizes documented per call);
+ *   - return value: 0 = TMI_OK, negative = TMI_ERR_*; never throws, never exits;
+ *   - dtype enum: TMI_F32 / TMI_BF16; every reduction accumulates in fp32.
+ */
+#ifndef TETHYS_MI_H
+#define TETHYS_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMI_OK 0
+#define TMI_ERR_INVALID (-1)   /* bad argument (shape, alignment, dtype combination) */
+#define TMI_ERR_LAUNCH (-2)    /* hipLaunchKernel reported an error */
+#define TMI_ERR_UNSUPPORTED (-3)
+
+#define TMI_F32 0
+#define TMI_BF16 1
+
+/* ABI version, bumped on any signature change. */
+int tmi_abi_version(void);
+/* Last HIP error string seen by a launch in this thread (host pointer, static storage). */
+const char* tmi_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Strided, batched GEMM with fused epilogue.  Replaces every tf.keras.layers.Dense call
+ * (W:89-92 q/k/v/out_proj, W:194-197 fc1/fc2, W:545 lm_head) and, through overlapping-row
+ * addressing of a channels-last padded buffer, tf.keras.layers.Conv1D (W:311-312) and the
+ * backward matmuls tape.gradient (W:833) derives from them.
+ *
+ *   for b in [0,nbatch):  C_b[m,n] = epi( sum_{kb<kbatch} sum_{k<K} A(b,kb,m,k) * B(b,kb,k,n) )
+ *   A(b,kb,m,k) = A[b*a_sb + kb*a_skb + m*a_sm + k*a_sk]      (element strides)
+ *   B(b,kb,k,n) = B[b*b_sb + kb*b_skb + k*b_sk + n*b_sn]
+ *   C_b[m,n]    = C[b*c_sb + m*ldc + n]
+ * epi(v), applied in this order:
+ *   v += bias[n]                      (bias f32 [N] or NULL)
+ *   if n < scale_cols: v *= scale     (W:141: q = (xWq+b) * head_dim^-0.5)
+ *   v += C_old                        (if accumulate != 0)
+ *   if aux_out: aux_out[..] = v       (pre-activation saved for backward; layout as C)
+ *   if act == 1: v = gelu_erf(v)      (tf.keras.activations.gelu, W:195,333,336)
+ *   if aux_in:  v *= gelu_erf'(aux_in[..])   (backward through GELU; layout as C)
+ *   if resid:   v += resid[b*r_sb + m*r_ld + n]  (residual add W:228,234 / PE add W:339)
+ * splitk > 1 partitions the (kb,k) range over extra workgroups and accumulates with
+ * fp32 atomics into a PRE-ZEROED fp32 C (no epilogue terms allowed).
+ * in_dtype: type of A and B; out_dtype: type of C, aux_*, resid.  Valid pairs:
+ * (F32,F32), (BF16,BF16), (BF16,F32).  fp32 inputs use the exact-fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32); bf16 inputs use v_mfma_f32_32x32x16_bf16.
+ */
+typedef struct tmi_gemm_desc {
+  const void* A; const void* B; void* C;
+  int64_t M, N, K;
+  int64_t a_sm, a_sk, b_sk, b_sn, ldc;
+  int64_t nbatch, a_sb, b_sb, c_sb;
+  int64_t kbatch, a_skb, b_skb;
+  const float* bias;
+  int64_t scale_cols; float scale;
+  int32_t accumulate;
+  int32_t act;
+  void* aux_out; const void* aux_in;
+  const void* resid; int64_t r_ld, r_sb;
+  int32_t splitk;
+  int32_t in_dtype, out_dtype;
+} tmi_gemm_desc;
+int tmi_gemm(const tmi_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last axis of x[rows, C].  Replaces
+ * tf.keras.layers.LayerNormalization(epsilon=1e-5) (W:214,216,245,249,253,322,392) and
+ * its gradient.  mean/rstd are fp32 [rows], saved for backward.
+ * Backward: dgamma/dbeta are produced as `nparts` fp32 partial rows in part[2*nparts*C]
+ * (first nparts*C = dgamma partials, then dbeta) and must be folded by tmi_reduce_rows;
+ * nparts = tmi_layernorm_bwd_parts(rows).
+ */
+int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                      float* mean, float* rstd, int64_t rows, int64_t C, float eps,
+                      int32_t dtype, void* stream);
+int64_t tmi_layernorm_bwd_parts(int64_t rows);
+int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                      const float* rstd, void* dx, float* part, int64_t rows, int64_t C,
+                      int32_t accumulate_dx, int32_t dtype, void* stream);
+
+/* out[n] (+)= sum_{p<P} part[p*N + n].  Deterministic second stage for the bias /
+ * gamma / beta gradients.  */
+int tmi_reduce_rows(const float* part, float* out, int64_t P, int64_t N, int32_t accumulate,
+                    void* stream);
+
+/* Column sums of dY[rows, N] (the bias gradient of a Dense / Conv1D layer).  Writes
+ * nparts = tmi_colsum_parts(rows) fp32 partial rows to part[nparts*N]. */
+int64_t tmi_colsum_parts(int64_t rows);
+int tmi_colsum(const void* dy, int64_t ld, float* part, int64_t rows, int64_t N,
+               int32_t dtype, void* stream);
+
+/* dx = dy * gelu_erf'(u), elementwise over n elements (backward of W:336 where the GELU
+ * output feeds the positional add rather than a GEMM). */
+int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Materialised-score softmax (fp32 "parity mode" attention, the reference's own graph
+ * shape: W:147-167).  s[rows, Tk] in place; row r belongs to query i = r % Tq.
+ * mask_mode 0: none.  mask_mode 1: the reference decoder's additive mask
+ * (1 - (1 - band_part(ones,-1,0))) * -1e9 (W:416-418, W:152-153): key j <= i gets -1e9
+ * added in fp32, keys j > i are left alone.
+ * Backward: ds = p * (dp - sum_j p*dp), dp in place.
+ */
+int tmi_softmax_fwd(float* s, int64_t rows, int64_t Tq, int64_t Tk, int32_t mask_mode, void* stream);
+int tmi_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t Tk, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused (flash-style) multi-head attention, bf16 in / fp32 accumulate, head_dim 64.
+ * Replaces W:147-171 (scores, mask, softmax, probs @ v, head merge) without ever
+ * materialising [B,H,Tq,Tk].  q/k/v/o are addressed as  ptr[b*sb + t*st + h*64 + d]
+ * (element strides), so q, k, v may be column slices of one fused QKV buffer.
+ * The query is expected pre-scaled (tmi_gemm scale_cols), as in W:141.
+ * stats: fp32 [B,H,Tq,2] = (row max m, 1/row sum) — kept separately because with the
+ * reference's -1e9 mask a fully masked row has m = -1e9, where m + log(l) is not
+ * representable in fp32.
+ * Backward is two kernels (no atomics, deterministic): dq pass owns query rows, dkv pass
+ * owns key rows; both recompute p from q, k and stats.  delta[B,H,Tq] = rowsum(do * o) is
+ * produced by tmi_attn_bwd itself into `delta` (fp32 workspace).
+ */
+typedef struct tmi_attn_desc {
+  const void* q; const void* k; const void* v; void* o;
+  int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
+  float* stats;
+  int64_t B, H, Tq, Tk;
+  int32_t mask_mode;           /* as tmi_softmax_fwd */
+  /* backward only */
+  const void* d_o; void* dq; void* dk; void* dv;
+  int64_t do_sb, do_st, dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
+  float* delta;
+  float dq_scale;              /* dq is multiplied by this on store (chain rule of W:141) */
+} tmi_attn_desc;
+int tmi_attn_fwd(const tmi_attn_desc* d, void* stream);
+int tmi_attn_bwd(const tmi_attn_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decoder token embedding + positional encoding (W:405-408) with the teacher-forcing
+ * shift of W:559-563 folded in: id(b,t) = t == 0 ? start_id : labels[b, t-1].
+ *   out[b,t,:] = table[id(b,t), :] + pe[t, :]
+ * Backward (gradient of tf.gather, densified): for every distinct id, dtable[id,:] =
+ * sum over its positions of dy, summed in position order (deterministic, no atomics).
+ * dtable must be zero on entry for rows that are not touched.
+ */
+int tmi_embed_fwd(const int32_t* labels, const float* table, const float* pe, void* out,
+                  int64_t B, int64_t S, int64_t D, int32_t start_id, int32_t dtype, void* stream);
+int tmi_embed_bwd(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
+                  int64_t D, int32_t start_id, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Shifted sparse softmax cross-entropy over logits[B*S, ld] (W:585-600):
+ * row (b,t) with t < S-1 is scored against labels[b, t+1]; row t = S-1 is unused.
+ *   row_loss[b*S+t] = logsumexp(logits) - logits[target]      (0 for unused rows)
+ *   logits <- dlogits = (softmax - onehot) * grad_scale       (0 for unused rows and for
+ *                                                              the pad columns [V, ld))
+ * grad_scale is 1 / (B*(S-1)) for the reference's reduce_mean.  tmi_mean_rows folds
+ * row_loss into loss[0] = sum(row_loss) * scale.
+ */
+int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss,
+                     int64_t B, int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream);
+int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-tensor Adam over a flat fp32 arena (tf.keras.optimizers.Adam, W:901; V:1271-1275).
+ *   g' = g * gscale                      (gscale: 1 for Whisper's SUM, 1/N for V:1231)
+ *   m <- b1 m + (1-b1) g' ; v <- b2 v + (1-b2) g'^2
+ *   eps_mode 0 (TF/Keras-V2): p <- p - lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+ *   eps_mode 1 (torch):       p <- p - lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
+ *   weight_decay (decoupled, AdamW) defaults to 0 in the reference.
+ * Algorithmic traffic: 28 B/param (read p,g,m,v; write p,m,v).
+ */
+int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
+                  float weight_decay, float gscale, void* stream);
+
+/* bf16 shadows of fp32 master weights: dst[r*ldd + c] = bf16(src[r*lds + c]) and the
+ * transposed form dst[c*ldd + r] = bf16(src[r*lds + c]); pad columns [cols, ldd) of the
+ * plain form are written as zero. */
+int tmi_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t rows,
+                  int64_t cols, void* stream);
+int tmi_transpose_cast_bf16(const float* src, int64_t lds, void* dst, int64_t ldd,
+                            int64_t rows, int64_t cols, void* stream);
+
+/* features [B, C, T] fp32 (W:792 layout) -> channels-last, time-padded
+ * out[b, pad_left + t, c] of shape [B, T + pad_left + pad_right, C] (pad rows zeroed):
+ * the tf.transpose of W:329 fused with the "same" padding of W:311. */
+int tmi_feat_to_channels_last(const float* feats, void* out, int64_t B, int64_t C, int64_t T,
+                              int64_t pad_left, int64_t pad_right, int32_t dtype, void* stream);
+
+/* sum of squares of n fp32 values into out[0] (+= if accumulate): tf.clip_by_global_norm
+ * (V:1243) first stage. */
+int tmi_sumsq(const float* x, float* out, int64_t n, int32_t accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TETHYS_MI_H */

@@ -1,0 +1,343 @@
+"""Per-kernel parity: every C-ABI entry point against the oracle's op-level restatement
+(oracle/whisper_oracle.py) or a closed-form fp64 expression, on seeded inputs.
+
+Tolerances: fp32 kernels vs fp64 reference: max|err| <= 2e-5 * max|ref| (forward) and
+1e-4 (gradients) — SURVEY.md 8(d).  bf16 kernels: inputs are rounded to bf16 first and the
+reference is evaluated in fp64 on those rounded inputs, so the tolerance only has to cover
+bf16 rounding of the OUTPUT plus fp32 accumulation: 1.5e-2 * max|ref|.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import whisper_oracle as O  # noqa: E402  (checker only)
+
+
+def _ops():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import ops
+    return ops
+
+
+def rel_err(got, ref):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+def tol(dtype, grad=False):
+    if dtype == torch.bfloat16:
+        return 1.5e-2
+    return 1e-4 if grad else 2e-5
+
+
+def rnd(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+    return x.to(dev)
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (200, 136, 96), (37, 51, 29), (300, 768, 768)])
+def test_gemm_layouts(dev, dtype, layout, shape):
+    ops = _ops()
+    M, N, K = shape
+    if dtype == torch.bfloat16 and (M, N, K) == (37, 51, 29):
+        pass  # scalar path (unaligned) is exercised for bf16 too
+    A = rnd((M, K), dtype, dev, 1)
+    B = rnd((K, N), dtype, dev, 2)
+    ref = A.double() @ B.double()
+    Cm = torch.empty((M, N), dtype=dtype, device=dev)
+    if layout == "nn":
+        ops.gemm(A, B, Cm, M, N, K, K, 1, N, 1, N)
+    elif layout == "nt":  # B stored [N,K]
+        Bt = B.t().contiguous()
+        ops.gemm(A, Bt, Cm, M, N, K, K, 1, 1, K, N)
+    else:  # A stored [K,M] (wgrad form), B natural
+        At = A.t().contiguous()
+        ops.gemm(At, B, Cm, M, N, K, 1, M, N, 1, N)
+    torch.cuda.synchronize()
+    assert rel_err(Cm, ref) <= (8e-3 if dtype == torch.bfloat16 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_chain(dev, dtype):
+    """bias, column scale, aux_out, gelu, residual — in the documented order."""
+    ops = _ops()
+    M, N, K = 260, 192, 128
+    A, B = rnd((M, K), dtype, dev, 3, 0.5), rnd((K, N), dtype, dev, 4, 0.5)
+    bias = rnd((N,), torch.float32, dev, 5)
+    R = rnd((M, N), dtype, dev, 6)
+    Cm = torch.empty((M, N), dtype=dtype, device=dev)
+    U = torch.empty_like(Cm)
+    ops.gemm(A, B, Cm, M, N, K, K, 1, N, 1, N, bias=bias, scale_cols=64, scale=0.125, act=1, aux_out=U,
+             resid=R, r_ld=N)
+    torch.cuda.synchronize()
+    u = A.double() @ B.double() + bias.double()
+    u[:, :64] *= 0.125
+    ref = O.gelu_erf(u) + R.double()
+    assert rel_err(U, u) <= tol(dtype) * 4
+    assert rel_err(Cm, ref) <= tol(dtype) * 4
+    # backward-through-GELU epilogue + accumulate
+    G = rnd((M, K), dtype, dev, 7, 0.5)
+    W = rnd((K, N), dtype, dev, 8, 0.5)
+    D = rnd((M, N), dtype, dev, 9)
+    D0 = D.clone()
+    ops.gemm(G, W, D, M, N, K, K, 1, N, 1, N, accumulate=True, aux_in=U)
+    torch.cuda.synchronize()
+    uu = U.double()
+    gp = 0.5 * (1 + torch.erf(uu / math.sqrt(2))) + uu * torch.exp(-0.5 * uu * uu) / math.sqrt(2 * math.pi)
+    ref2 = (G.double() @ W.double() + D0.double()) * gp
+    assert rel_err(D, ref2) <= tol(dtype) * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_conv_addressing(dev, dtype):
+    """Conv1D "same" as a GEMM over overlapping rows of a channels-last padded buffer,
+    checked against the oracle's conv1d_same (W:311-312 semantics), strides 1 and 2."""
+    ops = _ops()
+    Bn, T, Cin, Cout, k = 3, 50, 16, 40, 3
+    x = rnd((Bn, T, Cin), dtype, dev, 10)
+    w = rnd((k, Cin, Cout), dtype, dev, 11, 0.3)
+    bias = rnd((Cout,), torch.float32, dev, 12)
+    for stride in (1, 2):
+        Tout, pl, pr = O.same_pad(T, k, stride)
+        Tp = T + pl + pr
+        xp = torch.zeros((Bn, Tp + 2, Cin), dtype=dtype, device=dev)  # +2 rows slack
+        xp[:, pl:pl + T] = x
+        y = torch.empty((Bn, Tout, Cout), dtype=dtype, device=dev)
+        ops.gemm(xp, w, y, Tout, Cout, k * Cin, stride * Cin, 1, Cout, 1, Cout, nbatch=Bn,
+                 a_sb=(Tp + 2) * Cin, c_sb=Tout * Cout, bias=bias)
+        torch.cuda.synchronize()
+        ref = O.conv1d_same(x.double().cpu(), w.double().cpu(), bias.double().cpu(), stride)
+        assert rel_err(y, ref) <= tol(dtype) * 4
+
+
+def test_gemm_kbatch_splitk(dev):
+    """wgrad form with the reduction running over (batch, time) and split-K atomics."""
+    ops = _ops()
+    Bn, T, I, Nn = 4, 70, 96, 64
+    X = rnd((Bn, T, I), torch.bfloat16, dev, 13)
+    dY = rnd((Bn, T, Nn), torch.bfloat16, dev, 14)
+    ref = torch.einsum("bti,btn->in", X.double(), dY.double())
+    for splitk in (1, 3):
+        dW = torch.zeros((I, Nn), dtype=torch.float32, device=dev)
+        ops.gemm(X, dY, dW, I, Nn, T, 1, I, Nn, 1, Nn, kbatch=Bn, a_skb=T * I, b_skb=T * Nn, splitk=splitk)
+        torch.cuda.synchronize()
+        assert rel_err(dW, ref) <= 2e-3
+
+
+# ----------------------------------------------------------------------------- LayerNorm etc.
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,Cn", [(130, 768), (7, 384), (1000, 1280), (33, 32)])
+def test_layernorm(dev, dtype, rows, Cn):
+    ops = _ops()
+    x = rnd((rows, Cn), dtype, dev, 20, 2.0) + 0.5
+    gamma = rnd((Cn,), torch.float32, dev, 21) + 1.0
+    beta = rnd((Cn,), torch.float32, dev, 22)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, 1e-5)
+    xr = x.double().cpu().requires_grad_(True)
+    gr = gamma.double().cpu().requires_grad_(True)
+    br = beta.double().cpu().requires_grad_(True)
+    yr = O.layer_norm(xr, gr, br, 1e-5)
+    assert rel_err(y, yr) <= tol(dtype)
+    dy = rnd((rows, Cn), dtype, dev, 23)
+    yr.backward(dy.double().cpu())
+    P = ops.layernorm_bwd_parts(rows)
+    part = torch.empty(2 * P * Cn, dtype=torch.float32, device=dev)
+    dx = rnd((rows, Cn), dtype, dev, 24)
+    dx0 = dx.clone()
+    dg = torch.empty(Cn, dtype=torch.float32, device=dev)
+    db = torch.empty_like(dg)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, part, dg, db, accumulate_dx=True)
+    torch.cuda.synchronize()
+    assert rel_err(dx, xr.grad + dx0.double().cpu()) <= tol(dtype, True)
+    assert rel_err(dg, gr.grad) <= (1e-4 if dtype == torch.float32 else 2e-3)
+    assert rel_err(db, br.grad) <= (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_grad_and_gelu_bwd(dev, dtype):
+    ops = _ops()
+    rows, N = 1000, 768
+    dy = rnd((rows, N), dtype, dev, 30)
+    part = torch.empty(ops.colsum_parts(rows) * N, dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    ops.bias_grad(dy, part, db)
+    assert rel_err(db, dy.double().sum(0)) <= 1e-5
+    u = rnd((rows, N), dtype, dev, 31, 1.5)
+    dx = torch.empty_like(dy)
+    ops.gelu_bwd(dy, u, dx)
+    ur = u.double().cpu().requires_grad_(True)
+    O.gelu_erf(ur).backward(dy.double().cpu())
+    assert rel_err(dx, ur.grad) <= tol(dtype)
+
+
+@pytest.mark.parametrize("Tq,Tk,mask", [(100, 100, 1), (100, 1500, 0), (64, 257, 0), (5, 5, 1)])
+def test_softmax(dev, Tq, Tk, mask):
+    ops = _ops()
+    BH = 6
+    s = rnd((BH * Tq, Tk), torch.float32, dev, 40, 3.0)
+    ref_in = s.double().cpu().reshape(BH, Tq, Tk)
+    if mask:
+        m = torch.from_numpy(O.decoder_mask(Tq))
+        add = (1.0 - m) * -1e9
+        ref_in = torch.where(add != 0, (ref_in.float() + add).double(), ref_in)
+    pr = torch.softmax(ref_in, -1)
+    p = s.clone()
+    ops.softmax_fwd(p, BH * Tq, Tq, Tk, mask)
+    assert rel_err(p.reshape(BH, Tq, Tk), pr) <= 2e-6
+    if mask:
+        last = p.reshape(BH, Tq, Tk)[:, -1]
+        assert torch.all(last == last[:, :1]), "fully masked row must be exactly uniform"
+    dp = rnd((BH * Tq, Tk), torch.float32, dev, 41)
+    ref = pr * (dp.double().cpu().reshape(BH, Tq, Tk) - (pr * dp.double().cpu().reshape(BH, Tq, Tk)).sum(-1, keepdim=True))
+    ops.softmax_bwd(p, dp, BH * Tq, Tk)
+    assert rel_err(dp.reshape(BH, Tq, Tk), ref) <= 1e-5
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, mask_mode):
+    """fp64 reference of W:147-167 on [B,H,T,hd] inputs (q pre-scaled)."""
+    s = q @ k.transpose(-1, -2)
+    if mask_mode:
+        Tq = q.shape[2]
+        add = (1.0 - torch.from_numpy(O.decoder_mask(Tq))) * -1e9
+        s32 = s.float() + add
+        s = torch.where(add != 0, s + (s32.double() - s).detach(), s)
+    p = torch.softmax(s, -1)
+    return p @ v
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,mask", [(2, 3, 100, 100, 1), (1, 2, 200, 333, 0), (2, 2, 100, 1500, 0),
+                                            (1, 1, 31, 31, 1), (1, 12, 1500, 1500, 0)])
+def test_flash_attention(dev, B, H, Tq, Tk, mask):
+    ops = _ops()
+    D = H * 64
+    bf = torch.bfloat16
+    # fused QKV buffer [B,T,3D] for self-attention shapes, separate buffers otherwise
+    q = rnd((B, Tq, D), bf, dev, 50, 0.35)
+    k = rnd((B, Tk, D), bf, dev, 51)
+    v = rnd((B, Tk, D), bf, dev, 52)
+    o = torch.empty((B, Tq, D), dtype=bf, device=dev)
+    stats = torch.empty((B, H, Tq, 2), dtype=torch.float32, device=dev)
+    ops.attn_fwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats, B, H, Tq, Tk, mask)
+    torch.cuda.synchronize()
+
+    def heads(t, T):
+        return t.double().cpu().reshape(B, T, H, 64).permute(0, 2, 1, 3)
+
+    qr, kr, vr = heads(q, Tq).requires_grad_(True), heads(k, Tk).requires_grad_(True), heads(v, Tk).requires_grad_(True)
+    outr = _attn_ref(qr, kr, vr, mask)
+    ref_o = outr.permute(0, 2, 1, 3).reshape(B, Tq, D)
+    assert rel_err(o, ref_o) <= 2e-2
+    do = rnd((B, Tq, D), bf, dev, 53)
+    outr.backward(heads(do, Tq))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty((B, H, Tq), dtype=torch.float32, device=dev)
+    ops.attn_bwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats,
+                 (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D), (dv, 0, Tk * D, D), delta,
+                 B, H, Tq, Tk, mask, dq_scale=0.5)
+    torch.cuda.synchronize()
+
+    def merge(t, T):
+        return t.permute(0, 2, 1, 3).reshape(B, T, D)
+
+    assert rel_err(dv, merge(vr.grad, Tk)) <= 3e-2
+    assert rel_err(dk, merge(kr.grad, Tk)) <= 3e-2
+    assert rel_err(dq, 0.5 * merge(qr.grad, Tq)) <= 3e-2
+
+
+# ----------------------------------------------------------------------------- embed / xent / adam / misc
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embedding(dev, dtype):
+    ops = _ops()
+    B, S, D, V, start = 4, 12, 64, 128, 127
+    _, labels = O.create_dummy_pool(seed=3, n_mels=4, seq_len=8, max_target_length=S, num_samples=B)
+    lab = torch.from_numpy(labels).to(dev)
+    table = rnd((V, D), torch.float32, dev, 60)
+    pe = torch.from_numpy(O.positional_encoding(S, D)).to(dev)
+    out = torch.empty((B, S, D), dtype=dtype, device=dev)
+    ops.embed_fwd(lab, table, pe, out, B, S, D, start)
+    ids = O.decoder_input_ids(torch.from_numpy(labels), start).long()
+    ref = table.double().cpu()[ids] + pe.double().cpu()[:S]
+    assert rel_err(out, ref) <= (1e-7 if dtype == torch.float32 else 8e-3)
+    dy = rnd((B, S, D), dtype, dev, 61)
+    dt = torch.zeros((V, D), dtype=torch.float32, device=dev)
+    ops.embed_bwd(lab, dy, dt, B, S, D, start)
+    refg = torch.zeros((V, D), dtype=torch.float64)
+    refg.index_add_(0, ids.reshape(-1), dy.double().cpu().reshape(-1, D))
+    assert rel_err(dt, refg) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V,ld", [(51865, 51872), (128, 128)])
+def test_xent(dev, dtype, V, ld):
+    ops = _ops()
+    B, S = 3, 10
+    _, labels = O.create_dummy_pool(seed=4, n_mels=4, seq_len=8, max_target_length=S, num_samples=B)
+    lab = torch.from_numpy(labels).to(dev)
+    logits = torch.zeros((B * S, ld), dtype=dtype, device=dev)
+    logits[:, :V] = rnd((B * S, V), dtype, dev, 70, 2.0)
+    lr = logits[:, :V].double().cpu().reshape(B, S, V).requires_grad_(True)
+    loss = torch.nn.functional.cross_entropy(lr[:, :-1].reshape(-1, V), torch.from_numpy(labels)[:, 1:].long().reshape(-1))
+    loss.backward()
+    row_loss = torch.empty(B * S, dtype=torch.float32, device=dev)
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    gs = 1.0 / (B * (S - 1))
+    ops.xent_fwd_bwd(logits, ld, lab, row_loss, B, S, V, gs)
+    ops.sum_scale(row_loss, out, B * S, gs)
+    torch.cuda.synchronize()
+    assert abs(float(out) - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-6
+    assert rel_err(logits[:, :V].reshape(B, S, V), lr.grad) <= (1e-5 if dtype == torch.float32 else 8e-3)
+    assert float(logits[:, V:].abs().max()) == 0.0 if ld > V else True
+
+
+@pytest.mark.parametrize("eps_mode", [0, 1])
+def test_adam(dev, eps_mode):
+    ops = _ops()
+    n = 10007
+    p = rnd((n,), torch.float32, dev, 80)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    params = {"w": p.double().cpu().clone()}
+    st = O.AdamState()
+    for step in range(1, 4):
+        g = rnd((n,), torch.float32, dev, 80 + step, 0.01)
+        ops.adam_step(p, g, m, v, n, 1e-4, 0.9, 0.999, 1e-7, step, eps_mode=eps_mode)
+        O.adam_step(params, {"w": g.double().cpu()}, st, lr=1e-4, eps=1e-7, eps_mode="tf" if eps_mode == 0 else "torch")
+    torch.cuda.synchronize()
+    assert float((p.double().cpu() - params["w"]).abs().max()) <= 2e-7
+
+
+def test_casts_and_feats(dev):
+    ops = _ops()
+    R, Cc = 300, 205
+    src = rnd((R, Cc), torch.float32, dev, 90)
+    ldd = 208
+    d1 = torch.full((R, ldd), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.cast_bf16(src, Cc, d1, ldd, R, Cc)
+    assert torch.equal(d1[:, :Cc], src.to(torch.bfloat16)) and float(d1[:, Cc:].abs().max()) == 0.0
+    d2 = torch.empty((Cc, 304), dtype=torch.bfloat16, device=dev)
+    ops.transpose_cast_bf16(src, Cc, d2, 304, R, Cc)
+    assert torch.equal(d2[:, :R], src.t().to(torch.bfloat16))
+    Bn, Cn, T = 2, 80, 300
+    f = rnd((Bn, Cn, T), torch.float32, dev, 91)
+    for dtype in (torch.float32, torch.bfloat16):
+        out = torch.full((Bn, T + 2, Cn), 9.0, dtype=dtype, device=dev)
+        ops.feat_to_channels_last(f, out, Bn, Cn, T, 1, 1)
+        assert torch.equal(out[:, 1:T + 1], f.transpose(1, 2).to(dtype))
+        assert float(out[:, 0].abs().max()) == 0.0 and float(out[:, T + 1].abs().max()) == 0.0
+    x = rnd((100003,), torch.float32, dev, 92)
+    o = torch.empty(1, dtype=torch.float32, device=dev)
+    ops.sumsq(x, o, x.numel())
+    assert abs(float(o) - float((x.double() ** 2).sum())) <= 1e-4 * float((x.double() ** 2).sum())

@@ -1,0 +1,113 @@
+"""ctypes binding of libtethys_mi.so (the C ABI of include/tethys_mi.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``lib()`` raises if the
+shared object is missing or does not export every symbol the header declares.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+TMI_F32, TMI_BF16 = 0, 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtethys_mi.so")
+
+c_i64, c_i32, c_f32, c_vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_vp), ("B", c_vp), ("C", c_vp),
+        ("M", c_i64), ("N", c_i64), ("K", c_i64),
+        ("a_sm", c_i64), ("a_sk", c_i64), ("b_sk", c_i64), ("b_sn", c_i64), ("ldc", c_i64),
+        ("nbatch", c_i64), ("a_sb", c_i64), ("b_sb", c_i64), ("c_sb", c_i64),
+        ("kbatch", c_i64), ("a_skb", c_i64), ("b_skb", c_i64),
+        ("bias", c_vp),
+        ("scale_cols", c_i64), ("scale", c_f32),
+        ("accumulate", c_i32),
+        ("act", c_i32),
+        ("aux_out", c_vp), ("aux_in", c_vp),
+        ("resid", c_vp), ("r_ld", c_i64), ("r_sb", c_i64),
+        ("splitk", c_i32),
+        ("in_dtype", c_i32), ("out_dtype", c_i32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp),
+        ("q_sb", c_i64), ("q_st", c_i64), ("k_sb", c_i64), ("k_st", c_i64),
+        ("v_sb", c_i64), ("v_st", c_i64), ("o_sb", c_i64), ("o_st", c_i64),
+        ("stats", c_vp),
+        ("B", c_i64), ("H", c_i64), ("Tq", c_i64), ("Tk", c_i64),
+        ("mask_mode", c_i32),
+        ("d_o", c_vp), ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
+        ("do_sb", c_i64), ("do_st", c_i64), ("dq_sb", c_i64), ("dq_st", c_i64),
+        ("dk_sb", c_i64), ("dk_st", c_i64), ("dv_sb", c_i64), ("dv_st", c_i64),
+        ("delta", c_vp),
+        ("dq_scale", c_f32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tethys_mi.h declares
+SIGNATURES = {
+    "tmi_abi_version": (c_i32, []),
+    "tmi_last_error": (C.c_char_p, []),
+    "tmi_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
+    "tmi_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_layernorm_bwd_parts": (c_i64, [c_i64]),
+    "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "tmi_reduce_rows": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_colsum_parts": (c_i64, [c_i64]),
+    "tmi_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "tmi_softmax_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_softmax_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "tmi_attn_fwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
+    "tmi_attn_bwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
+    "tmi_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "tmi_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
+    "tmi_xent_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_sum_scale": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp]),
+    "tmi_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "tmi_transpose_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
+    "tmi_feat_to_channels_last": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_sumsq": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class TmiError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtethys_mi.so once; fail loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TmiError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    h = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise TmiError(f"libtethys_mi.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if h.tmi_abi_version() != ABI_VERSION:
+        raise TmiError(f"libtethys_mi.so ABI {h.tmi_abi_version()} != binding {ABI_VERSION}")
+    _lib = h
+    return h
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().tmi_last_error()
+        raise TmiError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

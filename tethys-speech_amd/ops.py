@@ -1,0 +1,194 @@
+"""Host-side operator wrappers: torch tensors in, C-ABI calls out.
+
+Each function resolves pointers / element strides from torch tensors (device memory is
+PyTorch's caching allocator: plumbing) and launches the HIP kernel on torch's current
+stream.  Nothing here computes on the host or falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import TMI_BF16, TMI_F32, AttnDesc, GemmDesc, check, lib
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return TMI_F32
+    if t.dtype == torch.bfloat16:
+        return TMI_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
+         kbatch=1, a_skb=0, b_skb=0, bias=None, scale_cols=0, scale=1.0, accumulate=False,
+         act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
+         a_off=0, b_off=0, c_off=0):
+    """C = epi(A·B); see tmi_gemm in include/tethys_mi.h.  ``*_off`` are element offsets
+    added to the tensors' base pointers (aux_* share c_off)."""
+    d = GemmDesc()
+    esA, esC = A.element_size(), Cm.element_size()
+    d.A = A.data_ptr() + a_off * esA
+    d.B = B.data_ptr() + b_off * B.element_size()
+    d.C = Cm.data_ptr() + c_off * esC
+    d.M, d.N, d.K = M, N, K
+    d.a_sm, d.a_sk, d.b_sk, d.b_sn, d.ldc = a_sm, a_sk, b_sk, b_sn, ldc
+    d.nbatch, d.a_sb, d.b_sb, d.c_sb = nbatch, a_sb, b_sb, c_sb
+    d.kbatch, d.a_skb, d.b_skb = kbatch, a_skb, b_skb
+    d.bias = ptr(bias)
+    d.scale_cols, d.scale = scale_cols, scale
+    d.accumulate = 1 if accumulate else 0
+    d.act = act
+    d.aux_out = None if aux_out is None else aux_out.data_ptr() + c_off * esC
+    d.aux_in = None if aux_in is None else aux_in.data_ptr() + c_off * esC
+    d.resid = ptr(resid)
+    d.r_ld, d.r_sb = r_ld, r_sb
+    d.splitk = splitk
+    assert A.dtype == B.dtype
+    d.in_dtype, d.out_dtype = dt(A), dt(Cm)
+    check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
+
+
+def linear(x2d, w, out, *, w_is_kn=True, **kw):
+    """out[M,N] = x2d[M,K] @ W with W given as [K,N] row-major (Keras Dense kernel layout)
+    when ``w_is_kn`` else as [N,K] row-major."""
+    M, K = x2d.shape
+    if w_is_kn:
+        N = w.shape[1]
+        b_sk, b_sn = w.stride(0), w.stride(1)
+    else:
+        N = w.shape[0]
+        b_sk, b_sn = w.stride(1), w.stride(0)
+    gemm(x2d, w, out, M, N, K, x2d.stride(0), x2d.stride(1), b_sk, b_sn, out.stride(0), **kw)
+
+
+def layernorm_fwd(x2d, gamma, beta, y2d, mean, rstd, eps):
+    rows, Cn = x2d.shape
+    check(lib().tmi_layernorm_fwd(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y2d.data_ptr(),
+                                  mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps, dt(x2d), stream()),
+          "tmi_layernorm_fwd")
+
+
+def layernorm_bwd_parts(rows: int) -> int:
+    return int(lib().tmi_layernorm_bwd_parts(rows))
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, part, dgamma, dbeta, accumulate_dx=False):
+    rows, Cn = x2d.shape
+    P = layernorm_bwd_parts(rows)
+    check(lib().tmi_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                  rstd.data_ptr(), dx2d.data_ptr(), part.data_ptr(), rows, Cn,
+                                  1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
+    s = stream()
+    check(lib().tmi_reduce_rows(part.data_ptr(), dgamma.data_ptr(), P, Cn, 0, s), "tmi_reduce_rows")
+    check(lib().tmi_reduce_rows(part.data_ptr() + P * Cn * 4, dbeta.data_ptr(), P, Cn, 0, s), "tmi_reduce_rows")
+
+
+def colsum_parts(rows: int) -> int:
+    return int(lib().tmi_colsum_parts(rows))
+
+
+def bias_grad(dy2d, part, dbias, accumulate=False):
+    """dbias[N] (+)= sum over rows of dy2d[rows, N]."""
+    rows, N = dy2d.shape
+    P = colsum_parts(rows)
+    check(lib().tmi_colsum(dy2d.data_ptr(), dy2d.stride(0), part.data_ptr(), rows, N, dt(dy2d), stream()),
+          "tmi_colsum")
+    check(lib().tmi_reduce_rows(part.data_ptr(), dbias.data_ptr(), P, N, 1 if accumulate else 0, stream()),
+          "tmi_reduce_rows")
+
+
+def gelu_bwd(dy, u, dx):
+    check(lib().tmi_gelu_bwd(dy.data_ptr(), u.data_ptr(), dx.data_ptr(), dy.numel(), dt(dy), stream()),
+          "tmi_gelu_bwd")
+
+
+def softmax_fwd(s, rows, Tq, Tk, mask_mode):
+    check(lib().tmi_softmax_fwd(s.data_ptr(), rows, Tq, Tk, mask_mode, stream()), "tmi_softmax_fwd")
+
+
+def softmax_bwd(p, dp, rows, Tk):
+    check(lib().tmi_softmax_bwd(p.data_ptr(), dp.data_ptr(), rows, Tk, stream()), "tmi_softmax_bwd")
+
+
+def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode):
+    """q,k,v,o: (tensor, element_offset, batch_stride, token_stride)."""
+    d = AttnDesc()
+    for name, (t, off, sb, st) in (("q", q), ("k", k), ("v", v), ("o", o)):
+        setattr(d, name, t.data_ptr() + off * t.element_size())
+        setattr(d, f"{name}_sb", sb)
+        setattr(d, f"{name}_st", st)
+    d.stats = stats.data_ptr()
+    d.B, d.H, d.Tq, d.Tk = B, H, Tq, Tk
+    d.mask_mode = mask_mode
+    return d
+
+
+def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0):
+    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode)
+    check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
+
+
+def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0):
+    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode)
+    for name, field, (t, off, sb, st) in (("d_o", "do", do), ("dq", "dq", dq), ("dk", "dk", dk), ("dv", "dv", dv)):
+        setattr(d, name, t.data_ptr() + off * t.element_size())
+        setattr(d, f"{field}_sb", sb)
+        setattr(d, f"{field}_st", st)
+    d.delta = delta.data_ptr()
+    d.dq_scale = dq_scale
+    check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
+
+
+def embed_fwd(labels, table, pe, out, B, S, D, start_id):
+    check(lib().tmi_embed_fwd(labels.data_ptr(), table.data_ptr(), pe.data_ptr(), out.data_ptr(), B, S, D,
+                              start_id, dt(out), stream()), "tmi_embed_fwd")
+
+
+def embed_bwd(labels, dy, dtable, B, S, D, start_id):
+    check(lib().tmi_embed_bwd(labels.data_ptr(), dy.data_ptr(), dtable.data_ptr(), B, S, D, start_id,
+                              dt(dy), stream()), "tmi_embed_bwd")
+
+
+def xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale):
+    check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
+                                 grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
+
+
+def sum_scale(x, out, n, scale):
+    check(lib().tmi_sum_scale(x.data_ptr(), out.data_ptr(), n, scale, stream()), "tmi_sum_scale")
+
+
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0):
+    check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
+                              eps, step, eps_mode, weight_decay, gscale, stream()), "tmi_adam_step")
+
+
+def cast_bf16(src, lds, dst, ldd, rows, cols, src_off=0, dst_off=0):
+    check(lib().tmi_cast_bf16(src.data_ptr() + 4 * src_off, lds, dst.data_ptr() + 2 * dst_off, ldd, rows, cols,
+                              stream()), "tmi_cast_bf16")
+
+
+def transpose_cast_bf16(src, lds, dst, ldd, rows, cols, src_off=0, dst_off=0):
+    check(lib().tmi_transpose_cast_bf16(src.data_ptr() + 4 * src_off, lds, dst.data_ptr() + 2 * dst_off, ldd,
+                                        rows, cols, stream()), "tmi_transpose_cast_bf16")
+
+
+def feat_to_channels_last(feats, out, B, Cn, T, pad_left, pad_right):
+    check(lib().tmi_feat_to_channels_last(feats.data_ptr(), out.data_ptr(), B, Cn, T, pad_left, pad_right,
+                                          dt(out), stream()), "tmi_feat_to_channels_last")
+
+
+def sumsq(x, out, n, accumulate=False):
+    check(lib().tmi_sumsq(x.data_ptr(), out.data_ptr(), n, 1 if accumulate else 0, stream()), "tmi_sumsq")
