@@ -257,6 +257,14 @@ def decoder_mask(S: int) -> np.ndarray:
     return 1.0 - np.tril(np.ones((S, S), dtype=np.float32))
 
 
+# True: masked scores take the fp32-rounded value of ``score + (-1e9)`` as in the reference
+# (the score is absorbed).  The finite-difference test sets it False: with the rounding the
+# forward is insensitive to a fully-masked row's scores while TF's (and autograd's) gradient
+# of the add is still 1, so the analytic gradient is deliberately not the FD derivative.
+FP32_MASK_ROUNDING = True
+MASK_VALUE = -1e9  # W:153; the FD test lowers it so fp64 keeps the masked row's score bits
+
+
 def mha(p, prefix, hidden, kv_states, mask, num_heads, attn_dropout=0.0, training=True):
     """W:106-176.  ``mask`` is the [1,S,S] tensor of W:416-418 or None.  The additive form
     (1 - mask) * -1e9 (W:152-153) is added in float32 so that, as in the reference, a
@@ -275,11 +283,14 @@ def mha(p, prefix, hidden, kv_states, mask, num_heads, attn_dropout=0.0, trainin
     q, k, v = split(q), split(k), split(v)
     scores = q @ k.transpose(-1, -2)  # W:147
     if mask is not None:
-        add = ((1.0 - mask.to(torch.float32)) * -1e9)  # W:152-153, float32
+        add = ((1.0 - mask.to(torch.float32)) * MASK_VALUE)  # W:152-153, float32
         summed32 = scores.to(torch.float32) + add  # fp32 rounding absorbs the score
         masked = (add != 0).expand_as(scores)
         # identity derivative wrt scores, as tf.add has; value = fp32-rounded sum
-        scores = torch.where(masked, scores + (summed32.to(scores.dtype) - scores).detach(), scores)
+        if FP32_MASK_ROUNDING:
+            scores = torch.where(masked, scores + (summed32.to(scores.dtype) - scores).detach(), scores)
+        else:
+            scores = scores + add.to(scores.dtype)
     probs = torch.softmax(scores, dim=-1)  # W:157
     probs = dropout(probs, attn_dropout, training)  # W:160
     ctx = probs @ v  # W:167

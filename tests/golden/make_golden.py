@@ -1,0 +1,40 @@
+"""Generates the golden fixtures under tests/golden/ from the oracle (run in the build
+container; the GPU box only reads the JSON).  The reference itself cannot be run (TensorFlow
+absent), so these vectors pin the HIP path to the oracle, not to a live TF.
+
+  python tests/golden/make_golden.py [--tiny-steps 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import whisper_oracle as O  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tiny_curve(steps, seed=1234, dtype=torch.float64):
+    cfg = O.make_config("tiny")
+    params = O.init_params(cfg, seed=seed, dtype=torch.float32)
+    params = {k: v.to(dtype) for k, v in params.items()}
+    feats, labels = O.create_dummy_pool(seed=seed)
+    t0 = time.time()
+    losses, _ = O.train_steps(cfg, params, feats, labels, 2, steps, lr=1e-4)
+    return {"model": "whisper-tiny (384/6h/1536/4+4, W:859-865)", "batch_size": 2, "steps": steps, "seed": seed,
+            "lr": 1e-4, "oracle_dtype": str(dtype), "losses": losses, "oracle_seconds": time.time() - t0}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tiny-steps", type=int, default=10)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    out = tiny_curve(a.tiny_steps)
+    json.dump(out, open(os.path.join(HERE, "whisper_tiny_b2_10steps.json"), "w"), indent=1)
+    print(out)

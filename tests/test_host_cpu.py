@@ -1,0 +1,170 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host logic
+(arena layout, strategy buckets, TF_CONFIG parsing, dataset batching), and the N>1
+gradient all-reduce path with world_size-2 gloo."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "tethys_mi.h")).read()
+    declared = set(re.findall(r"\b(tmi_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"tmi_gemm_desc", "tmi_attn_desc"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    h = _lib.lib()  # loads, binds all symbols, checks the ABI version
+    assert h.tmi_abi_version() == _lib.ABI_VERSION
+    # struct layouts agree with the C compiler's
+    src = '#include "%s"\n#include <stdio.h>\nint main(){printf("%%zu %%zu", sizeof(tmi_gemm_desc), sizeof(tmi_attn_desc));}' % os.path.join(ROOT, "include", "tethys_mi.h")
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", os.path.join(td, "s.c"), "-o", os.path.join(td, "s")])
+        a, b = subprocess.check_output([os.path.join(td, "s")]).split()
+    assert int(a) == ctypes.sizeof(_lib.GemmDesc) and int(b) == ctypes.sizeof(_lib.AttnDesc)
+
+
+def test_bad_arguments_fail_loudly_without_a_gpu():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import _lib
+    h = _lib.lib()
+    assert h.tmi_gemm(None, None) == -1
+    assert h.tmi_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 1.0, None) == -1
+    with pytest.raises(_lib.TmiError):
+        _lib.check(h.tmi_layernorm_fwd(None, None, None, None, None, None, 0, 0, 1e-5, 0, None), "ln")
+
+
+def test_arena_layout_and_reference_views():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import whisper
+    from oracle import whisper_oracle as O
+    cfg = whisper.make_config("small", d_model=64, encoder_attention_heads=1, decoder_attention_heads=1, d_ff=128,
+                              vocab_size=131, encoder_layers=2, decoder_layers=2, n_mels=8)
+    a = whisper.ParamArena(cfg, "cpu")
+    ocfg = O.make_config("small", d_model=64, encoder_attention_heads=1, decoder_attention_heads=1, d_ff=128,
+                         vocab_size=131, encoder_layers=2, decoder_layers=2, n_mels=8)
+    shapes = O.param_shapes(ocfg)
+    views = a.ref_views(a.p)
+    assert set(views) == set(shapes)
+    for k, s in shapes.items():
+        assert tuple(views[k].shape) == tuple(s), k
+    assert a.n_params == O.param_count(ocfg)
+    assert all(o % 4 == 0 for o in a.offsets.values())
+    # forward order: lm_head last, conv1 first -> backward fills the arena from the end
+    assert a.names[0] == "encoder.conv1.kernel" and a.names[-1] == "lm_head.kernel"
+    p = O.init_params(ocfg)
+    a.load_ref(p)
+    back = a.ref_views(a.p)
+    for k in p:
+        assert torch.equal(back[k], p[k])
+    full = whisper.ParamArena(whisper.make_config("small"), "meta") if False else None  # (size only below)
+    assert whisper.make_config("tiny").d_model == 384 and whisper.make_config("large").encoder_layers == 32
+
+
+def test_strategy_buckets_and_env():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    s = D.DataParallelStrategy(0, 1, bucket_bytes=4 * 100)
+    b = s.buckets(250)
+    assert b == [(150, 250), (50, 150), (0, 50)]
+    assert D.task_from_env({}) == ("worker", 0, 0, 1)
+    assert D.task_from_env({"RANK": "3", "WORLD_SIZE": "8"}) == ("worker", 3, 3, 8)
+    tfc = '{"cluster":{"chief":["a:1"],"worker":["b:1","c:1"]},"task":{"type":"worker","index":1}}'
+    assert D.task_from_env({"TF_CONFIG": tfc}) == ("worker", 1, 2, 3)
+    tfc = '{"cluster":{"chief":["a:1"],"worker":["b:1"]},"task":{"type":"chief","index":0}}'
+    assert D.task_from_env({"TF_CONFIG": tfc}) == ("chief", 0, 0, 2)
+
+
+def test_dataset_batching_matches_reference_recipe():
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import data
+    from oracle import whisper_oracle as O
+    ds = data.create_dummy_dataset(8, n_mels=4, seq_len=16, max_target_length=100, device="cpu")
+    f, l = O.create_dummy_pool(seed=1234, n_mels=4, seq_len=16)
+    it = O.batches(f, l, 8)
+    for _ in range(9):
+        a, b = next(ds)
+        fa, la = next(it)
+        assert np.array_equal(a.numpy(), fa) and np.array_equal(b.numpy(), la)
+    d0 = data.create_dummy_dataset(4, n_mels=4, seq_len=16, device="cpu", rank=0, world=2, drop_remainder=True)
+    d1 = data.create_dummy_dataset(4, n_mels=4, seq_len=16, device="cpu", rank=1, world=2, drop_remainder=True)
+    for step in range(8):
+        a0, _ = next(d0)
+        a1, _ = next(d1)
+        s = (step % 6) * 8
+        assert np.array_equal(a0.numpy(), f[s:s + 4]) and np.array_equal(a1.numpy(), f[s + 4:s + 8])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    from oracle import whisper_oracle as O
+    torch.set_num_threads(2)
+    strat = D.DataParallelStrategy(rank, world, backend="gloo", bucket_bytes=4 * 1000)
+    cfg = O.make_config("small", d_model=32, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=64,
+                        vocab_size=128, encoder_layers=1, decoder_layers=1, n_mels=8, n_ctx=12,
+                        decoder_start_token_id=127, dropout=0.0, attention_dropout=0.0)
+    f, l = O.create_dummy_pool(seed=2, n_mels=8, seq_len=24, max_target_length=6, num_samples=4)
+    p = O.init_params(cfg, seed=100 + rank, dtype=torch.float64)  # deliberately different per rank
+    names = sorted(p)
+    flat = torch.cat([p[k].reshape(-1) for k in names])
+    strat.broadcast_parameters(flat)  # C4
+    off = 0
+    for k in names:
+        n = p[k].numel()
+        p[k] = flat[off:off + n].view_as(p[k]).clone()
+        off += n
+    loss, g = O.loss_and_grads(p, torch.from_numpy(f[2 * rank:2 * rank + 2]), torch.from_numpy(l[2 * rank:2 * rank + 2]), cfg)
+    gflat = torch.cat([g[k].reshape(-1) for k in names])
+    strat.all_reduce_gradients(gflat)  # C1 (bucketed)
+    tot = strat.reduce_sum(loss.reshape(1).clone())  # C2
+    q.put((rank, gflat.numpy(), float(tot), flat.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_equals_single_process_sum():
+    from oracle import whisper_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (r0, g0, l0, p0), (r1, g1, l1, p1) = res
+    assert np.array_equal(g0, g1) and l0 == l1 and np.array_equal(p0, p1)
+    cfg = O.make_config("small", d_model=32, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=64,
+                        vocab_size=128, encoder_layers=1, decoder_layers=1, n_mels=8, n_ctx=12,
+                        decoder_start_token_id=127, dropout=0.0, attention_dropout=0.0)
+    f, l = O.create_dummy_pool(seed=2, n_mels=8, seq_len=24, max_target_length=6, num_samples=4)
+    p = O.init_params(cfg, seed=100, dtype=torch.float64)  # rank 0's values were broadcast
+    names = sorted(p)
+    la, ga = O.loss_and_grads(p, torch.from_numpy(f[:2]), torch.from_numpy(l[:2]), cfg)
+    lb, gb = O.loss_and_grads(p, torch.from_numpy(f[2:4]), torch.from_numpy(l[2:4]), cfg)
+    ref = torch.cat([(ga[k] + gb[k]).reshape(-1) for k in names]).numpy()
+    assert np.allclose(g0, ref, rtol=1e-12, atol=1e-15)
+    assert l0 == pytest.approx(float(la) + float(lb), rel=1e-12)

@@ -297,7 +297,7 @@ def test_xent(dev, dtype, V, ld):
     ops.xent_fwd_bwd(logits, ld, lab, row_loss, B, S, V, gs)
     ops.sum_scale(row_loss, out, B * S, gs)
     torch.cuda.synchronize()
-    assert abs(float(out) - float(loss)) <= 1e-5 * abs(float(loss)) + 1e-6
+    assert abs(float(out) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach())) + 1e-6
     assert rel_err(logits[:, :V].reshape(B, S, V), lr.grad) <= (1e-5 if dtype == torch.float32 else 8e-3)
     assert float(logits[:, V:].abs().max()) == 0.0 if ld > V else True
 
@@ -316,7 +316,8 @@ def test_adam(dev, eps_mode):
         ops.adam_step(p, g, m, v, n, 1e-4, 0.9, 0.999, 1e-7, step, eps_mode=eps_mode)
         O.adam_step(params, {"w": g.double().cpu()}, st, lr=1e-4, eps=1e-7, eps_mode="tf" if eps_mode == 0 else "torch")
     torch.cuda.synchronize()
-    assert float((p.double().cpu() - params["w"]).abs().max()) <= 2e-7
+    # 3 steps on |p| up to ~4: a couple of fp32 ulps (2.4e-7 at |p| in [2,4))
+    assert float((p.double().cpu() - params["w"]).abs().max()) <= 1e-6
 
 
 def test_casts_and_feats(dev):

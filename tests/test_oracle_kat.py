@@ -1,0 +1,184 @@
+"""Known-answer tests that pin the oracle: the reference has no golden
+vectors, so these closed forms, derived from the source text of
+speech_jobs/whisper_dist.py, are what anchors the restatement."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as O
+
+
+def test_positional_encoding_closed_form():
+    for d in (8, 768):
+        pe = O.positional_encoding(50, d)
+        for p in (0, 1, 7, 49):
+            for i in (0, 2, d - 2):
+                ang = p * math.exp(-i * math.log(10000.0) / d)
+                assert pe[p, i] == pytest.approx(math.sin(ang), abs=1e-6)
+                assert pe[p, i + 1] == pytest.approx(math.cos(ang), abs=1e-6)
+    assert O.positional_encoding(3, 8).dtype == np.float32
+
+
+def test_decoder_mask_is_inverted():
+    for S in (1, 4, 100):
+        m = O.decoder_mask(S)
+        add = (1.0 - m) * -1e9
+        for i in range(S):
+            for j in range(S):
+                assert (add[i, j] == 0.0) == (j > i)  # only strictly-future keys stay visible
+    # fully masked last row -> exactly uniform probabilities in fp32
+    S = 5
+    cfg = O.make_config("small", d_model=8, decoder_attention_heads=1)
+    p = {f"a.{n}.kernel": torch.randn(8, 8) for n in ("q_proj", "k_proj", "v_proj", "out_proj")}
+    p.update({f"a.{n}.bias": torch.zeros(8) for n in ("q_proj", "k_proj", "v_proj", "out_proj")})
+    x = torch.randn(1, S, 8)
+    q = (x @ p["a.q_proj.kernel"]) * 8 ** -0.5
+    k = x @ p["a.k_proj.kernel"]
+    s = (q @ k.transpose(-1, -2)) + torch.from_numpy((1.0 - O.decoder_mask(S)) * -1e9)
+    pr = torch.softmax(s, -1)
+    assert torch.all(pr[0, -1] == pr[0, -1, 0])
+    assert float(pr[0, 0, 0]) == 0.0 and float(pr[0, 0, 1:].sum()) == pytest.approx(1.0)
+
+
+def test_same_padding_lengths_and_splits():
+    assert O.same_pad(3000, 3, 1) == (3000, 1, 1)
+    assert O.same_pad(3000, 3, 2) == (1500, 0, 1)
+    assert O.same_pad(100, 128, 1) == (100, 63, 64)
+    T = 32000
+    outs = []
+    for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        T = O.same_pad(T, k, s)[0]
+        outs.append(T)
+    assert outs == [6400, 3200, 1600, 800, 400, 200, 100]
+    T = 80000
+    for k, s in zip((10, 3, 3, 3, 3, 2, 2), (5, 2, 2, 2, 2, 2, 2)):
+        T = O.same_pad(T, k, s)[0]
+    assert T == 250
+
+
+def test_conv1d_same_hand_vector():
+    # k=3, s=2, T=4: out=2, pad (0,1); y[t] = sum_kk x[2t+kk] * w[kk]
+    x = torch.tensor([[[1.0], [2.0], [3.0], [4.0]]])
+    w = torch.tensor([[[1.0]], [[10.0]], [[100.0]]])
+    y = O.conv1d_same(x, w, None, 2)
+    assert y.flatten().tolist() == [321.0, 43.0]
+    # k=3, s=1: pad (1,1)
+    y = O.conv1d_same(x, w, None, 1)
+    assert y.flatten().tolist() == [210.0, 321.0, 432.0, 43.0]
+
+
+def test_label_recipe():
+    f, l = O.create_dummy_pool(seed=1234)
+    assert f.shape == (50, 80, 3000) and f.dtype == np.float32
+    assert l.shape == (50, 100) and l.dtype == np.int32
+    for row in l:
+        assert row[0] == 1
+        L = int(np.max(np.nonzero(row)[0])) + 1
+        assert 50 <= L < 90 and row[L - 1] == 2
+        assert np.all((row[1:L - 1] >= 3) & (row[1:L - 1] < 100))
+        assert np.all(row[L:] == 0)
+    b = O.batches(f, l, 8)
+    sizes = [next(b)[0].shape[0] for _ in range(8)]
+    assert sizes == [8, 8, 8, 8, 8, 8, 2, 8]  # no drop_remainder (W:815)
+
+
+def test_parameter_counts():
+    assert O.param_count(O.make_config("tiny")) == 56_933_376
+    assert O.param_count(O.make_config("small")) == 147_781_632
+    assert O.param_count(O.make_config("large")) == 1_607_321_600
+
+
+def test_decoder_input_shift():
+    lab = torch.tensor([[1, 5, 6, 2, 0]], dtype=torch.int32)
+    assert O.decoder_input_ids(lab, 50257).tolist() == [[50257, 1, 5, 6, 2]]
+
+
+def _small():
+    cfg = O.make_config("small", d_model=32, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=64,
+                        vocab_size=128, encoder_layers=1, decoder_layers=2, n_mels=8, n_ctx=12,
+                        decoder_start_token_id=127, dropout=0.0, attention_dropout=0.0)
+    f, l = O.create_dummy_pool(seed=2, n_mels=8, seq_len=24, max_target_length=6, num_samples=4)
+    return cfg, f, l
+
+
+def test_init_loss_is_about_log_vocab():
+    cfg, f, l = _small()
+    p = O.init_params(cfg, dtype=torch.float64)
+    loss, _ = O.forward_loss(p, torch.from_numpy(f[:2]), torch.from_numpy(l[:2]), cfg)
+    assert abs(float(loss) - math.log(cfg.vocab_size)) < 0.6
+
+
+def test_double_shift_scoring():
+    """logits[:, t] is scored against labels[:, t+1] (W:585-586) and the last position is unused."""
+    cfg, f, l = _small()
+    p = O.init_params(cfg, dtype=torch.float64)
+    ft, lt = torch.from_numpy(f[:2]), torch.from_numpy(l[:2])
+    loss, logits = O.forward_loss(p, ft, lt, cfg)
+    lp = torch.log_softmax(logits, -1)
+    manual = -sum(lp[b, t, int(lt[b, t + 1])] for b in range(2) for t in range(5)) / 10
+    assert float(loss) == pytest.approx(float(manual), rel=1e-12)
+
+
+def test_finite_difference_gradients_fp64(monkeypatch):
+    monkeypatch.setattr(O, "FP32_MASK_ROUNDING", False)  # see the flag's comment in the oracle
+    monkeypatch.setattr(O, "MASK_VALUE", -1e4)  # -1e9 + score quantises the score even in fp64
+    cfg, f, l = _small()
+    p = O.init_params(cfg, dtype=torch.float64)
+    ft, lt = torch.from_numpy(f[:2]), torch.from_numpy(l[:2])
+    _, g = O.loss_and_grads(p, ft, lt, cfg)
+    rng = np.random.default_rng(0)
+    for name in ["encoder.conv1.kernel", "encoder.conv2.bias", "encoder.layers.0.self_attn.k_proj.kernel",
+                 "encoder.layers.0.final_layer_norm.gamma", "decoder.layers.1.encoder_attn.v_proj.kernel",
+                 "decoder.layers.0.feed_forward.fc1.bias", "decoder.embed_tokens.embeddings", "lm_head.kernel"]:
+        w = p[name]
+        gi = g[name]
+        flat = torch.nonzero(gi.abs() > gi.abs().max() * 0.2)
+        idx = tuple(flat[int(rng.integers(0, len(flat)))].tolist())
+        old = float(w[idx])
+        eps = 1e-6
+        w[idx] = old + eps
+        lp = float(O.forward_loss(p, ft, lt, cfg)[0])
+        w[idx] = old - eps
+        lm = float(O.forward_loss(p, ft, lt, cfg)[0])
+        w[idx] = old
+        assert (lp - lm) / (2 * eps) == pytest.approx(float(gi[idx]), rel=2e-5, abs=1e-9), name
+
+
+def test_adam_three_hand_computed_steps():
+    g = [torch.tensor([0.1, -0.2, 0.0, 0.3], dtype=torch.float64)] * 3
+    for mode in ("tf", "torch"):
+        p = {"w": torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64)}
+        st = O.AdamState()
+        w = np.array([1.0, 2.0, 3.0, 4.0])
+        m = np.zeros(4)
+        v = np.zeros(4)
+        for t in range(1, 4):
+            O.adam_step(p, {"w": g[t - 1]}, st, lr=1e-2, eps=1e-7, eps_mode=mode)
+            gn = g[t - 1].numpy()
+            m = 0.9 * m + 0.1 * gn
+            v = 0.999 * v + 0.001 * gn * gn
+            if mode == "tf":
+                w = w - 1e-2 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t) * m / (np.sqrt(v) + 1e-7)
+            else:
+                w = w - 1e-2 * (m / (1 - 0.9 ** t)) / (np.sqrt(v / (1 - 0.999 ** t)) + 1e-7)
+            assert np.allclose(p["w"].numpy(), w, rtol=0, atol=1e-15)
+    # constant gradient => first TF step moves by ~lr (sign), zero gradient does not move
+    p = {"w": torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64)}
+    O.adam_step(p, {"w": g[0]}, O.AdamState(), lr=1e-2, eps=1e-7)
+    assert p["w"][2] == 3.0 and float(p["w"][0]) == pytest.approx(1.0 - 1e-2, abs=1e-6)  # eps shifts it by lr*eps/(sqrt(1-b2)|g|)
+
+
+def test_data_parallel_sum_semantics():
+    """N replicas x B == gradient SUM and loss SUM (no 1/N), W:829-836 + W:848."""
+    cfg, f, l = _small()
+    p = O.init_params(cfg, dtype=torch.float64)
+    l2, _ = O.train_steps(cfg, {k: v.clone() for k, v in p.items()}, f, l, 2, 1, n_replicas=2)
+    la, ga = O.loss_and_grads(p, torch.from_numpy(f[:2]), torch.from_numpy(l[:2]), cfg)
+    lb, gb = O.loss_and_grads(p, torch.from_numpy(f[2:4]), torch.from_numpy(l[2:4]), cfg)
+    assert l2[0] == pytest.approx(float(la) + float(lb), rel=1e-12)
+    l1, g1 = O.loss_and_grads(p, torch.from_numpy(f[:4]), torch.from_numpy(l[:4]), cfg)
+    # sum of two half-batch mean-loss gradients = 2 x gradient of the full-batch mean loss
+    for k in ga:
+        assert torch.allclose(ga[k] + gb[k], 2 * g1[k], rtol=1e-9, atol=1e-12)

@@ -1,0 +1,665 @@
+"""Whisper encoder-decoder training step on the HIP kernels (host orchestration).
+
+Mirrors the reference's operator API for this path (speech_jobs/whisper_dist.py, "W:"):
+``WhisperConfig`` (W:10-45), ``create_whisper_model(model_type)`` (W:852-890) and a model
+object whose ``forward_backward(features, labels)`` does what ``model(features,
+labels=..., training=True)`` + ``tape.gradient`` do at W:826-833.  The forward/backward is
+written out by hand (no autograd): every tensor op is a C-ABI call from ``ops``.
+
+Two precisions:
+  "fp32"  parity mode — fp32 activations, exact-fp32 MFMA GEMMs reading the fp32 master
+          weights, attention in the reference's own materialised-score shape (W:147-167).
+  "bf16"  perf mode — bf16 activations and bf16 weight shadows, fused flash attention,
+          fp32 accumulation, fp32 gradients/optimizer state.
+Dropout (W:29-30) is not applied in either mode (rates forced to 0): TF's RNG stream cannot
+be reproduced, so a step with dropout has no parity definition.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- config
+@dataclass
+class WhisperConfig:  # W:10-45
+    d_model: int = 768
+    encoder_layers: int = 4
+    encoder_attention_heads: int = 12
+    decoder_layers: int = 4
+    decoder_attention_heads: int = 12
+    d_ff: int = 3072
+    n_mels: int = 80
+    n_ctx: int = 1500
+    vocab_size: int = 51865
+    max_target_positions: int = 448
+    dropout: float = 0.1
+    attention_dropout: float = 0.1
+    activation_dropout: float = 0.0
+    layer_norm_eps: float = 1e-5
+    pad_token_id: int = 0
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+    decoder_start_token_id: int = 50257
+
+
+_SIZES = {  # W:859-886
+    "tiny": dict(d_model=384, encoder_layers=4, encoder_attention_heads=6, decoder_layers=4,
+                 decoder_attention_heads=6, d_ff=1536),
+    "base": dict(d_model=512, encoder_layers=6, encoder_attention_heads=8, decoder_layers=6,
+                 decoder_attention_heads=8, d_ff=2048),
+    "small": dict(),
+    "medium": dict(d_model=1024, encoder_layers=24, encoder_attention_heads=16, decoder_layers=24,
+                   decoder_attention_heads=16, d_ff=4096),
+    "large": dict(d_model=1280, encoder_layers=32, encoder_attention_heads=20, decoder_layers=32,
+                  decoder_attention_heads=20, d_ff=5120),
+}
+
+
+def make_config(model_type: str = "small", **overrides) -> WhisperConfig:
+    cfg = WhisperConfig()
+    for k, v in _SIZES.get(model_type, {}).items():
+        setattr(cfg, k, v)
+    for k, v in overrides.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def same_pad(T: int, k: int, s: int) -> Tuple[int, int, int]:
+    """TensorFlow "SAME": -> (T_out, pad_left, pad_right)."""
+    out = -(-T // s)
+    total = max((out - 1) * s + k - T, 0)
+    return out, total // 2, total - total // 2
+
+
+def positional_encoding(max_len: int, d_model: int) -> np.ndarray:
+    """W:49-69."""
+    pe = np.zeros((max_len, d_model))
+    position = np.arange(0, max_len)[:, np.newaxis]
+    div_term = np.exp(np.arange(0, d_model, 2) * -(np.log(10000.0) / d_model))
+    pe[:, 0::2] = np.sin(position * div_term)
+    pe[:, 1::2] = np.cos(position * div_term)
+    return pe.astype(np.float32)
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- parameters
+class ParamArena:
+    """All trainable parameters in ONE flat fp32 buffer (plus same-shaped grad / Adam m / v
+    buffers), in forward order so that backward fills the gradient arena from its end
+    towards its start: all-reduce buckets are contiguous slices, ready in reverse order.
+
+    Storage tensors fuse the reference's separate q/k/v Dense kernels column-wise
+    ([d, 3d] for self-attention, [d, 2d] k|v for cross-attention); ``ref_views`` exposes
+    them under the reference's own variable paths as strided views.
+    """
+
+    def __init__(self, cfg: WhisperConfig, device):
+        self.cfg = cfg
+        d, ff, V = cfg.d_model, cfg.d_ff, cfg.vocab_size
+        spec: List[Tuple[str, Tuple[int, ...]]] = []
+
+        def ln(p):
+            spec.append((f"{p}.gamma", (d,)))
+            spec.append((f"{p}.beta", (d,)))
+
+        def ffn(p):
+            spec.extend([(f"{p}.fc1.kernel", (d, ff)), (f"{p}.fc1.bias", (ff,)),
+                         (f"{p}.fc2.kernel", (ff, d)), (f"{p}.fc2.bias", (d,))])
+
+        spec.append(("encoder.conv1.kernel", (3, cfg.n_mels, d)))
+        spec.append(("encoder.conv1.bias", (d,)))
+        spec.append(("encoder.conv2.kernel", (3, d, d)))
+        spec.append(("encoder.conv2.bias", (d,)))
+        for i in range(cfg.encoder_layers):
+            p = f"encoder.layers.{i}"
+            ln(f"{p}.self_attn_layer_norm")
+            spec.extend([(f"{p}.self_attn.qkv.kernel", (d, 3 * d)), (f"{p}.self_attn.qkv.bias", (3 * d,)),
+                         (f"{p}.self_attn.out_proj.kernel", (d, d)), (f"{p}.self_attn.out_proj.bias", (d,))])
+            ln(f"{p}.final_layer_norm")
+            ffn(f"{p}.feed_forward")
+        ln("encoder.layer_norm")
+        spec.append(("decoder.embed_tokens.embeddings", (V, d)))
+        for i in range(cfg.decoder_layers):
+            p = f"decoder.layers.{i}"
+            ln(f"{p}.self_attn_layer_norm")
+            spec.extend([(f"{p}.self_attn.qkv.kernel", (d, 3 * d)), (f"{p}.self_attn.qkv.bias", (3 * d,)),
+                         (f"{p}.self_attn.out_proj.kernel", (d, d)), (f"{p}.self_attn.out_proj.bias", (d,))])
+            ln(f"{p}.encoder_attn_layer_norm")
+            spec.extend([(f"{p}.encoder_attn.q_proj.kernel", (d, d)), (f"{p}.encoder_attn.q_proj.bias", (d,)),
+                         (f"{p}.encoder_attn.kv.kernel", (d, 2 * d)), (f"{p}.encoder_attn.kv.bias", (2 * d,)),
+                         (f"{p}.encoder_attn.out_proj.kernel", (d, d)), (f"{p}.encoder_attn.out_proj.bias", (d,))])
+            ln(f"{p}.final_layer_norm")
+            ffn(f"{p}.feed_forward")
+        ln("decoder.layer_norm")
+        spec.append(("lm_head.kernel", (d, V)))
+
+        self.offsets: Dict[str, int] = {}
+        self.shapes: Dict[str, Tuple[int, ...]] = {}
+        off = 0
+        for name, shape in spec:
+            self.offsets[name] = off
+            self.shapes[name] = shape
+            off += _round_up(int(np.prod(shape)), 4)  # keep every tensor 16-byte aligned
+        self.numel = off
+        self.n_params = sum(int(np.prod(s)) for s in self.shapes.values())
+        self.p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.names = [n for n, _ in spec]
+
+    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
+        o, s = self.offsets[name], self.shapes[name]
+        return buf[o:o + int(np.prod(s))].view(*s)
+
+    def param(self, name):
+        return self.view(self.p, name)
+
+    def grad(self, name):
+        return self.view(self.g, name)
+
+    def ref_views(self, buf: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Views of ``buf`` keyed by the reference's variable paths (oracle.param_shapes)."""
+        d = self.cfg.d_model
+        out: Dict[str, torch.Tensor] = {}
+        for name in self.names:
+            t = self.view(buf, name)
+            if name.endswith(".qkv.kernel"):
+                base = name[:-len("qkv.kernel")]
+                for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                    out[f"{base}{n}.kernel"] = t[:, j * d:(j + 1) * d]
+            elif name.endswith(".qkv.bias"):
+                base = name[:-len("qkv.bias")]
+                for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+                    out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
+            elif name.endswith(".kv.kernel"):
+                base = name[:-len("kv.kernel")]
+                for j, n in enumerate(("k_proj", "v_proj")):
+                    out[f"{base}{n}.kernel"] = t[:, j * d:(j + 1) * d]
+            elif name.endswith(".kv.bias"):
+                base = name[:-len("kv.bias")]
+                for j, n in enumerate(("k_proj", "v_proj")):
+                    out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
+            else:
+                out[name] = t
+        return out
+
+    def load_ref(self, params: Dict[str, torch.Tensor]):
+        """Copy a reference-keyed dict (e.g. the oracle's init_params) into the arena."""
+        views = self.ref_views(self.p)
+        missing = set(views) ^ set(params)
+        if missing:
+            raise KeyError(f"parameter name mismatch: {sorted(missing)[:4]} ...")
+        for k, v in views.items():
+            v.copy_(params[k].to(torch.float32))
+
+    def init_keras_defaults(self, seed: int = 1234):
+        """Keras default initialisers (SURVEY a-14): glorot-uniform kernels (per reference
+        tensor, so each fused q/k/v slice uses fan_in+fan_out of its own [d,d] kernel), zero
+        biases, Embedding U(-0.05, 0.05), LayerNorm gamma=1 / beta=0."""
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for name, v in self.ref_views(self.p).items():
+            shape = tuple(v.shape)
+            if name.endswith(".kernel"):
+                if len(shape) == 3:
+                    fan_in, fan_out = shape[0] * shape[1], shape[0] * shape[2]
+                else:
+                    fan_in, fan_out = shape
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * lim)
+            elif name.endswith(".embeddings"):
+                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * 0.05)
+            elif name.endswith(".gamma"):
+                v.fill_(1.0)
+            else:
+                v.zero_()
+
+
+# ----------------------------------------------------------------------------- model
+class WhisperForConditionalGeneration:
+    """W:536-616 (training path only).  Holds parameters, bf16 shadows and all activation
+    workspaces; sized lazily for a batch size on first use."""
+
+    def __init__(self, config: WhisperConfig, device="cuda:0", precision: str = "bf16", seed: int = 1234):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        ops.lib()  # fail loudly now if the HIP library is missing
+        self.config = config
+        self.device = torch.device(device)
+        self.precision = precision
+        self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.arena = ParamArena(config, self.device)
+        self.arena.init_keras_defaults(seed)
+        d = config.d_model
+        if d % config.encoder_attention_heads or d % config.decoder_attention_heads:
+            raise ValueError("d_model must divide by the head counts")
+        if precision == "bf16" and (d // config.encoder_attention_heads != 64 or d // config.decoder_attention_heads != 64):
+            raise ValueError("the fused attention kernel is built for head_dim 64")
+        self.pe_enc = torch.from_numpy(positional_encoding(config.n_ctx, d)).to(self.device)
+        self.pe_dec = torch.from_numpy(positional_encoding(config.max_target_positions, d)).to(self.device)
+        self.pe_enc_t = self.pe_enc.to(self.dtype)
+        self._ws_key = None
+        self.ws: Dict[str, torch.Tensor] = {}
+        # bf16 shadows (perf mode): one flat buffer, natural [in, out] layout, ld padded to 8
+        self.shadow: Dict[str, torch.Tensor] = {}
+        self.shadow_ld: Dict[str, int] = {}
+        if precision == "bf16":
+            total = 0
+            plan = []
+            for name in self.arena.names:
+                if name.endswith(".kernel"):
+                    shape = self.arena.shapes[name]
+                    rows = int(np.prod(shape[:-1]))
+                    ld = _round_up(shape[-1], 8)
+                    plan.append((name, rows, shape[-1], ld, total))
+                    total += rows * ld
+            self._shadow_buf = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+            self._shadow_plan = plan
+            for name, rows, cols, ld, off in plan:
+                self.shadow[name] = self._shadow_buf[off:off + rows * ld].view(rows, ld)
+                self.shadow_ld[name] = ld
+            self.refresh_shadows()
+
+    # -- weights ---------------------------------------------------------------------
+    def refresh_shadows(self):
+        """bf16 copies of the fp32 master kernels (call after every optimizer step)."""
+        if self.precision != "bf16":
+            return
+        for name, rows, cols, ld, off in self._shadow_plan:
+            ops.cast_bf16(self.arena.p, cols, self._shadow_buf, ld, rows, cols,
+                          src_off=self.arena.offsets[name], dst_off=off)
+
+    def W(self, name) -> Tuple[torch.Tensor, int]:
+        """(2-D weight tensor [in, out(+pad)], leading dimension) in the compute dtype."""
+        if self.precision == "bf16":
+            return self.shadow[name], self.shadow_ld[name]
+        shape = self.arena.shapes[name]
+        rows = int(np.prod(shape[:-1]))
+        return self.arena.param(name).view(rows, shape[-1]), shape[-1]
+
+    # -- workspaces --------------------------------------------------------------------
+    def _buf(self, name, shape, dtype=None, zero=False):
+        t = self.ws.get(name)
+        dtype = dtype or self.dtype
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.ws[name] = t
+        return t
+
+    def _prepare(self, B: int, T_in: int, S: int):
+        key = (B, T_in, S)
+        if self._ws_key == key:
+            return
+        self.ws.clear()
+        self._ws_key = key
+        cfg = self.config
+        if S > cfg.max_target_positions:
+            raise ValueError("target length exceeds max_target_positions")
+        self.T1, self.pl1, self.pr1 = same_pad(T_in, 3, 1)
+        self.T, self.pl2, self.pr2 = same_pad(self.T1, 3, 2)
+        if self.T > cfg.n_ctx:
+            raise ValueError("encoder length exceeds n_ctx")
+        d, ff = cfg.d_model, cfg.d_ff
+        self.Tp0 = T_in + self.pl1 + self.pr1
+        self.Tp1 = self.T1 + self.pl2 + self.pr2
+        slack = 2  # rows of zero slack so the padded-K tail reads of the last window stay in bounds
+        f32 = torch.float32
+        z = dict(zero=True)
+        self._buf("xp0", (B, self.Tp0 + slack, cfg.n_mels), **z)
+        self._buf("h1pad", (B, self.Tp1 + slack, d), **z)
+        self._buf("u1pad", (B, self.Tp1 + slack, d), **z)
+        self._buf("dh1pad", (B, self.Tp1 + slack, d), **z)
+        self._buf("u2", (B, self.T, d))
+        self._buf("du2pad", (B, self.T + 1, d), **z)
+        R, Rd = B * self.T, B * S
+        for side, L, rows in (("enc", cfg.encoder_layers, R), ("dec", cfg.decoder_layers, Rd)):
+            for i in range(L):
+                p = f"{side}{i}."
+                self._buf(p + "x_in", (rows, d))
+                self._buf(p + "xn1", (rows, d))
+                self._buf(p + "qkv", (rows, 3 * d))
+                self._buf(p + "ctx", (rows, d))
+                self._buf(p + "x_mid", (rows, d))
+                self._buf(p + "xn2", (rows, d))
+                self._buf(p + "u", (rows, ff))
+                self._buf(p + "g", (rows, ff))
+                for s_ in ("ln1", "ln2"):
+                    self._buf(p + s_ + ".mean", (rows,), f32)
+                    self._buf(p + s_ + ".rstd", (rows,), f32)
+                if side == "dec":
+                    self._buf(p + "x_mid2", (rows, d))
+                    self._buf(p + "xn3", (rows, d))
+                    self._buf(p + "qc", (rows, d))
+                    self._buf(p + "kvc", (R, 2 * d))
+                    self._buf(p + "ctxc", (rows, d))
+                    self._buf(p + "ln3.mean", (rows,), f32)
+                    self._buf(p + "ln3.rstd", (rows,), f32)
+        self._buf("enc_x", (R, d))
+        self._buf("enc_out", (R, d))
+        self._buf("enc_ln.mean", (R,), f32)
+        self._buf("enc_ln.rstd", (R,), f32)
+        self._buf("dec_x", (Rd, d))
+        self._buf("dec_out", (Rd, d))
+        self._buf("dec_ln.mean", (Rd,), f32)
+        self._buf("dec_ln.rstd", (Rd,), f32)
+        self.ldl = _round_up(cfg.vocab_size, 32)
+        self._buf("logits", (Rd, self.ldl), **z)
+        self._buf("row_loss", (Rd,), f32)
+        self._buf("loss", (1,), f32)
+        # backward scratch, shared by every layer
+        Rm = max(R, Rd)
+        self._buf("dres_enc", (R, d))
+        self._buf("dres_dec", (Rd, d))
+        self._buf("d_enc_out", (R, d))
+        self._buf("dtmp", (Rm, d))
+        self._buf("dctx", (Rm, d))
+        self._buf("dqkv", (Rm, 3 * d))
+        self._buf("dkvc", (R, 2 * d))
+        self._buf("dU", (Rm, ff))
+        nparts = max(ops.layernorm_bwd_parts(Rm), ops.colsum_parts(Rm), ops.colsum_parts(B * (self.Tp1 + slack)))
+        self._buf("part", (2 * nparts * max(3 * d, ff),), f32)
+        He, Hd = cfg.encoder_attention_heads, cfg.decoder_attention_heads
+        if self.precision == "bf16":
+            for i in range(cfg.encoder_layers):
+                self._buf(f"enc{i}.stats", (B, He, self.T, 2), f32)
+            for i in range(cfg.decoder_layers):
+                self._buf(f"dec{i}.stats", (B, Hd, S, 2), f32)
+                self._buf(f"dec{i}.statsc", (B, Hd, S, 2), f32)
+            self._buf("delta", (B, max(He, Hd), max(self.T, S)), f32)
+        else:
+            for i in range(cfg.encoder_layers):
+                self._buf(f"enc{i}.P", (B, He, self.T, self.T), f32)
+            for i in range(cfg.decoder_layers):
+                self._buf(f"dec{i}.P", (B, Hd, S, S), f32)
+                self._buf(f"dec{i}.Pc", (B, Hd, S, self.T), f32)
+            self._buf("dP", (B, max(He, Hd), max(self.T, S), self.T), f32)
+
+    # -- building blocks -----------------------------------------------------------------
+    def _dense_fwd(self, x2d, wname, out2d, n_off=0, n_cols=None, **epi):
+        """out = x @ W[:, n_off:n_off+n_cols] (+bias ...).  W is the Keras [in, out] kernel."""
+        w, ldw = self.W(wname)
+        K = w.shape[0]
+        N = n_cols if n_cols is not None else self.arena.shapes[wname][-1]
+        bias = None
+        bname = wname.replace(".kernel", ".bias")
+        if bname in self.arena.offsets:
+            bias = self.arena.param(bname)[n_off:n_off + N]
+        ops.gemm(x2d, w, out2d, x2d.shape[0], N, K, x2d.stride(0), 1, ldw, 1, out2d.stride(0),
+                 b_off=n_off, bias=bias, **epi)
+
+    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None):
+        """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in))."""
+        w, ldw = self.W(wname)
+        K_in = w.shape[0]
+        N = self.arena.shapes[wname][-1]
+        M = x2d.shape[0]
+        dW = self.arena.grad(wname).view(K_in, N)
+        tiles = -(-K_in // 128) * -(-N // 128)
+        ktiles = -(-M // (64 if self.precision == "bf16" else 32))
+        splitk = 1
+        if tiles < 192:
+            splitk = max(1, min(ktiles // 4, -(-384 // tiles)))
+        ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N, splitk=splitk)
+        bname = wname.replace(".kernel", ".bias")
+        if bname in self.arena.offsets:
+            ops.bias_grad(dy2d, self.ws["part"], self.arena.grad(bname))
+        if dx2d is not None:
+            ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
+                     accumulate=accumulate_dx, aux_in=aux_in)
+
+    def _ln_fwd(self, x2d, pname, y2d, stat):
+        a = self.arena
+        ops.layernorm_fwd(x2d, a.param(pname + ".gamma"), a.param(pname + ".beta"), y2d,
+                          self.ws[stat + ".mean"], self.ws[stat + ".rstd"], self.config.layer_norm_eps)
+
+    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate):
+        a = self.arena
+        ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
+                          dx2d, self.ws["part"], a.grad(pname + ".gamma"), a.grad(pname + ".beta"),
+                          accumulate_dx=accumulate)
+
+    # attention: q/k/v given as (tensor2d, column offset); rows are (b, t) with Tq / Tk per batch
+    def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask):
+        d = self.config.d_model
+        (qt, qo), (kt, ko), (vt, vo) = q, k, v
+        if self.precision == "bf16":
+            ops.attn_fwd((qt, qo, Tq * qt.stride(0), qt.stride(0)), (kt, ko, Tk * kt.stride(0), kt.stride(0)),
+                         (vt, vo, Tk * vt.stride(0), vt.stride(0)), (ctx2d, 0, Tq * d, d),
+                         self.ws[key], B, H, Tq, Tk, mask)
+            return
+        P = self.ws[key]
+        hd = d // H
+        for b in range(B):
+            ops.gemm(qt, kt, P, Tq, Tk, hd, qt.stride(0), 1, 1, kt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd,
+                     c_sb=Tq * Tk, a_off=b * Tq * qt.stride(0) + qo, b_off=b * Tk * kt.stride(0) + ko,
+                     c_off=b * H * Tq * Tk)
+        ops.softmax_fwd(P, B * H * Tq, Tq, Tk, mask)
+        for b in range(B):
+            ops.gemm(P, vt, ctx2d, Tq, hd, Tk, Tk, 1, vt.stride(0), 1, d, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
+                     a_off=b * H * Tq * Tk, b_off=b * Tk * vt.stride(0) + vo, c_off=b * Tq * d)
+
+    def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask):
+        d = self.config.d_model
+        hd = d // H
+        scaling = hd ** -0.5
+        (qt, qo), (kt, ko), (vt, vo) = q, k, v
+        (dqt, dqo), (dkt, dko), (dvt, dvo) = dq, dk, dv
+        if self.precision == "bf16":
+            def m(t, off, T):
+                return (t, off, T * t.stride(0), t.stride(0))
+            ops.attn_bwd(m(qt, qo, Tq), m(kt, ko, Tk), m(vt, vo, Tk), m(ctx2d, 0, Tq), self.ws[key],
+                         m(dctx2d, 0, Tq), m(dqt, dqo, Tq), m(dkt, dko, Tk), m(dvt, dvo, Tk), self.ws["delta"],
+                         B, H, Tq, Tk, mask, dq_scale=scaling)
+            return
+        P = self.ws[key]
+        dP = self.ws["dP"]
+        for b in range(B):
+            po = b * H * Tq * Tk
+            # dP = dctx · Vᵀ
+            ops.gemm(dctx2d, vt, dP, Tq, Tk, hd, d, 1, 1, vt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd, c_sb=Tq * Tk,
+                     a_off=b * Tq * d, b_off=b * Tk * vt.stride(0) + vo, c_off=po)
+            # dV = Pᵀ · dctx
+            ops.gemm(P, dctx2d, dvt, Tk, hd, Tq, 1, Tk, d, 1, dvt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
+                     a_off=po, b_off=b * Tq * d, c_off=b * Tk * dvt.stride(0) + dvo)
+        ops.softmax_bwd(P, dP, B * H * Tq, Tk)
+        for b in range(B):
+            po = b * H * Tq * Tk
+            # dQ = dS · K  (then * scaling: chain rule of W:141, folded into this GEMM's column scale)
+            ops.gemm(dP, kt, dqt, Tq, hd, Tk, Tk, 1, kt.stride(0), 1, dqt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
+                     c_sb=hd, a_off=po, b_off=b * Tk * kt.stride(0) + ko, c_off=b * Tq * dqt.stride(0) + dqo,
+                     scale_cols=hd, scale=scaling)
+            # dK = dSᵀ · Q
+            ops.gemm(dP, qt, dkt, Tk, hd, Tq, 1, Tk, qt.stride(0), 1, dkt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
+                     c_sb=hd, a_off=po, b_off=b * Tq * qt.stride(0) + qo, c_off=b * Tk * dkt.stride(0) + dko)
+
+    # -- forward -------------------------------------------------------------------------
+    def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0):
+        """One replica's forward + backward (W:826-833).  features [B, n_mels, T_in] fp32,
+        labels [B, S] int32, both on the device.  Gradients land in ``arena.g`` (which is
+        zeroed first); returns the device scalar loss (mean over B*(S-1), W:600)."""
+        cfg = self.config
+        B, Cn, T_in = features.shape
+        S = labels.shape[1]
+        if Cn != cfg.n_mels or labels.shape[0] != B:
+            raise ValueError("bad batch shapes")
+        if features.dtype != torch.float32 or labels.dtype != torch.int32:
+            raise TypeError("features must be float32 and labels int32")
+        self._prepare(B, T_in, S)
+        ws, a, d, ff = self.ws, self.arena, cfg.d_model, cfg.d_ff
+        T, He, Hd = self.T, cfg.encoder_attention_heads, cfg.decoder_attention_heads
+        scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
+        a.g.zero_()
+
+        # ---- encoder stem (W:329-339)
+        xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
+        ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
+        w1, ld1 = self.W("encoder.conv1.kernel")
+        ops.gemm(xp0, w1, h1pad, self.T1, d, 3 * Cn, Cn, 1, ld1, 1, d, nbatch=B, a_sb=xp0.stride(0),
+                 c_sb=h1pad.stride(0), c_off=self.pl2 * d, bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
+        w2, ld2 = self.W("encoder.conv2.kernel")
+        x = ws["enc0.x_in"] if cfg.encoder_layers else ws["enc_x"]
+        ops.gemm(h1pad, w2, x, T, d, 3 * d, 2 * d, 1, ld2, 1, d, nbatch=B, a_sb=h1pad.stride(0), c_sb=T * d,
+                 bias=a.param("encoder.conv2.bias"), act=1, aux_out=ws["u2"], resid=self.pe_enc_t, r_ld=d, r_sb=0)
+
+        # ---- encoder layers (W:218-236)
+        for i in range(cfg.encoder_layers):
+            p, k = f"encoder.layers.{i}", f"enc{i}."
+            x_in = ws[k + "x_in"]
+            self._ln_fwd(x_in, p + ".self_attn_layer_norm", ws[k + "xn1"], k + "ln1")
+            self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_e)
+            qkv = ws[k + "qkv"]
+            self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
+                           ws[k + "ctx"], B, He, T, T, 0)
+            self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
+            self._ln_fwd(ws[k + "x_mid"], p + ".final_layer_norm", ws[k + "xn2"], k + "ln2")
+            self._dense_fwd(ws[k + "xn2"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
+            nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.encoder_layers else ws["enc_x"]
+            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid"], r_ld=d)
+        self._ln_fwd(ws["enc_x"], "encoder.layer_norm", ws["enc_out"], "enc_ln")
+        enc_out = ws["enc_out"]
+
+        # ---- decoder (W:394-466); ids = [start, labels[:, :-1]] (W:559-563) inside the kernel
+        y = ws["dec0.x_in"] if cfg.decoder_layers else ws["dec_x"]
+        ops.embed_fwd(labels, a.param("decoder.embed_tokens.embeddings"), self.pe_dec, y, B, S, d,
+                      cfg.decoder_start_token_id)
+        for i in range(cfg.decoder_layers):
+            p, k = f"decoder.layers.{i}", f"dec{i}."
+            x_in = ws[k + "x_in"]
+            self._ln_fwd(x_in, p + ".self_attn_layer_norm", ws[k + "xn1"], k + "ln1")
+            self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_d)
+            qkv = ws[k + "qkv"]
+            self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
+                           ws[k + "ctx"], B, Hd, S, S, 1)
+            self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
+            # cross attention (W:278-290): k/v projections of the encoder output in every layer
+            self._ln_fwd(ws[k + "x_mid"], p + ".encoder_attn_layer_norm", ws[k + "xn2"], k + "ln2")
+            self._dense_fwd(ws[k + "xn2"], p + ".encoder_attn.q_proj.kernel", ws[k + "qc"], scale_cols=d, scale=scal_d)
+            self._dense_fwd(enc_out, p + ".encoder_attn.kv.kernel", ws[k + "kvc"])
+            kvc = ws[k + "kvc"]
+            self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0), (kvc, 0), (kvc, d),
+                           ws[k + "ctxc"], B, Hd, S, T, 0)
+            self._dense_fwd(ws[k + "ctxc"], p + ".encoder_attn.out_proj.kernel", ws[k + "x_mid2"],
+                            resid=ws[k + "x_mid"], r_ld=d)
+            self._ln_fwd(ws[k + "x_mid2"], p + ".final_layer_norm", ws[k + "xn3"], k + "ln3")
+            self._dense_fwd(ws[k + "xn3"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
+            nxt = ws[f"dec{i + 1}.x_in"] if i + 1 < cfg.decoder_layers else ws["dec_x"]
+            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid2"], r_ld=d)
+        self._ln_fwd(ws["dec_x"], "decoder.layer_norm", ws["dec_out"], "dec_ln")
+
+        # ---- LM head + shifted cross-entropy (W:579-600); logits become dlogits in place
+        V = cfg.vocab_size
+        logits = ws["logits"]
+        wl, ldw = self.W("lm_head.kernel")
+        ops.gemm(ws["dec_out"], wl, logits, B * S, V, d, d, 1, ldw, 1, self.ldl)
+        gs = loss_scale / (B * (S - 1))
+        ops.xent_fwd_bwd(logits, self.ldl, labels, ws["row_loss"], B, S, V, gs)
+        ops.sum_scale(ws["row_loss"], ws["loss"], B * S, 1.0 / (B * (S - 1)))
+
+        # ================= backward =================
+        dres = ws["dres_dec"]
+        dW = a.grad("lm_head.kernel")
+        ops.gemm(ws["dec_out"], logits, dW, d, V, B * S, 1, d, self.ldl, 1, V)
+        dtmp = ws["dtmp"][:B * S]
+        ops.gemm(logits, wl, dtmp, B * S, d, V, self.ldl, 1, 1, ldw, d)
+        self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
+
+        d_enc = ws["d_enc_out"]
+        first_cross = True
+        for i in reversed(range(cfg.decoder_layers)):
+            p, k = f"decoder.layers.{i}", f"dec{i}."
+            Rd = B * S
+            dU, dt_, dctx, dqkv = ws["dU"][:Rd], ws["dtmp"][:Rd], ws["dctx"][:Rd], ws["dqkv"][:Rd]
+            # FFN
+            self._dense_bwd(ws[k + "g"], dres, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+            self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
+            self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True)
+            # cross attention
+            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctx)
+            kvc, dkvc, dqc = ws[k + "kvc"], ws["dkvc"], ws["dtmp"][:Rd]
+            self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0), (kvc, 0), (kvc, d),
+                           ws[k + "ctxc"], dctx, (dqc, 0), (dkvc, 0), (dkvc, d), B, Hd, S, T, 0)
+            self._dense_bwd(enc_out, dkvc, p + ".encoder_attn.kv.kernel", d_enc, accumulate_dx=not first_cross)
+            first_cross = False
+            dxn2 = ws["dctx"][:Rd]
+            self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
+            self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True)
+            # self attention
+            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
+            qkv = ws[k + "qkv"]
+            self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
+                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1)
+            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
+            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+        ops.embed_bwd(labels, dres, a.grad("decoder.embed_tokens.embeddings"), B, S, d, cfg.decoder_start_token_id)
+
+        # ---- encoder backward
+        dres = ws["dres_enc"]
+        if cfg.decoder_layers == 0:
+            d_enc.zero_()
+        self._ln_bwd(d_enc, ws["enc_x"], "encoder.layer_norm", dres, "enc_ln", False)
+        R = B * T
+        for i in reversed(range(cfg.encoder_layers)):
+            p, k = f"encoder.layers.{i}", f"enc{i}."
+            dU, dt_, dctx, dqkv = ws["dU"][:R], ws["dtmp"][:R], ws["dctx"][:R], ws["dqkv"][:R]
+            self._dense_bwd(ws[k + "g"], dres, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+            self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_)
+            self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True)
+            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
+            qkv = ws[k + "qkv"]
+            self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
+                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0)
+            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
+            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+
+        # ---- stem backward: x0 = gelu(u2) + PE ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(x)
+        du2pad, dh1pad = ws["du2pad"], ws["dh1pad"]
+        du2 = du2pad[:, 1:]  # row 0 of every batch stays zero (the "t-1" term of the first output)
+        for b in range(B):  # gelu_bwd needs contiguous spans: one per batch
+            ops.gelu_bwd(dres[b * T:(b + 1) * T], ws["u2"][b], du2[b])
+        part = ws["part"]
+        gb2 = a.grad("encoder.conv2.bias")
+        for b in range(B):
+            ops.bias_grad(du2[b], part, gb2, accumulate=b > 0)
+        gw2 = a.grad("encoder.conv2.kernel").view(3 * d, d)
+        ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
+                 b_skb=du2pad.stride(0), b_off=d)
+        sd = du2pad.stride(0)
+        # even padded rows u = 2j: dY[j]·W0ᵀ + dY[j-1]·W2ᵀ  (kbatch walks the two kernel taps)
+        ops.gemm(du2pad, w2, dh1pad, T, d, d, d, 1, 1, ld2, 2 * d, nbatch=B, a_sb=sd, c_sb=dh1pad.stride(0),
+                 kbatch=2, a_skb=-d, b_skb=2 * d * ld2, a_off=d, aux_in=u1pad)
+        # odd padded rows u = 2j + 1: dY[j]·W1ᵀ
+        ops.gemm(du2pad, w2, dh1pad, T, d, d, d, 1, 1, ld2, 2 * d, nbatch=B, a_sb=sd, c_sb=dh1pad.stride(0),
+                 a_off=d, b_off=d * ld2, c_off=d, aux_in=u1pad)
+        if self.pl2:
+            dh1pad[:, :self.pl2].zero_()
+        dh1pad[:, self.pl2 + self.T1:].zero_()
+        gb1 = a.grad("encoder.conv1.bias")
+        for b in range(B):
+            ops.bias_grad(dh1pad[b, self.pl2:self.pl2 + self.T1], part, gb1, accumulate=b > 0)
+        gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
+        ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
+                 b_skb=dh1pad.stride(0), b_off=self.pl2 * d)
+        return ws["loss"]
+
+    def __call__(self, features, labels=None, training=True):
+        """Reference call surface (W:829): returns {"loss": ...}.  Gradients are a side effect."""
+        if not training or labels is None:
+            raise NotImplementedError("only the training path (labels given, training=True) is on the hot path")
+        return {"loss": self.forward_backward(features, labels)}
+
+
+def create_whisper_model(model_type: str = "small", device="cuda:0", precision: str = "bf16", seed: int = 1234,
+                         **overrides) -> WhisperForConditionalGeneration:
+    """W:852-890."""
+    return WhisperForConditionalGeneration(make_config(model_type, **overrides), device=device,
+                                           precision=precision, seed=seed)
