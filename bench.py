@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/sec/node of the Whisper small-ref training step.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = forward + backward + gradient all-reduce (SUM, N > 1) + Adam + bf16 shadow
+refresh on one synthetic batch already resident in HBM (BASELINE.json configs[1]: Whisper
+"small" as the reference defines it — 768/12h/3072, 4+4 layers, W:13-18 — bf16 compute,
+per-GPU batch 8, 30 s clips = [8, 80, 3000] features + [8, 100] labels).  Weak scaling: the
+per-GPU batch is fixed, value = 30 s * 8 * N * K / max-over-ranks wall time.
+
+Also reported on the same JSON line:
+  roofline      the dominant kernel class (the MFMA GEMM, tmi_gemm): algorithmic FLOPs of
+                every tmi_gemm launch in a step / their device time measured with HIP events
+                recorded on the launch stream during an instrumented pass of the same steps,
+                against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the
+                host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up +
+                2 timed steps of the same model and clip length).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 30.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+GF_PER_SAMPLE = 449.1           # fwd+bwd algorithmic GFLOP per 30 s sample, small-ref
+
+
+def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
+    import torch
+    from oracle import whisper_oracle as O  # checker, timed as the CPU baseline only
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    params = O.init_params(cfg, seed=1234, dtype=torch.float32)
+    feats, labels = O.create_dummy_pool(seed=1234, seq_len=seq_len, num_samples=sample_batch * (steps + 1))
+    O.train_steps(cfg, params, feats, labels, sample_batch, 1)  # warm-up
+    t0 = time.time()
+    O.train_steps(cfg, params, feats[sample_batch:], labels[sample_batch:], sample_batch, steps)
+    dt = time.time() - t0
+    return {"value": CLIP_SECONDS * sample_batch * steps / dt, "unit": "audio-seconds/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, "
+                      f"batch {sample_batch}, {steps} timed steps after 1 warm-up, {dt / steps:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--model_type", default="small")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    from tethys_speech_amd import ops, optim, train, whisper
+    from tethys_speech_amd.data import create_dummy_dataset
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    strategy = D.DataParallelStrategy(rank, world, backend="nccl")
+
+    model = whisper.create_whisper_model(args.model_type, device=dev, precision=args.precision, seed=1234)
+    strategy.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    opt = optim.Adam(learning_rate=1e-4)
+    ds = create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True)
+    it = iter(ds)
+
+    def one_step():
+        return train.distributed_train_step(strategy, model, next(it), opt)
+
+    for _ in range(args.warmup):
+        one_step()
+    strategy.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    torch.cuda.synchronize()
+    strategy.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    last_loss = float(loss.item())
+
+    roof = None
+    if not args.no_roofline:
+        # instrumented pass: HIP events around every tmi_gemm launch, on the launch stream
+        ops.PROFILE = ops.GemmProfile()
+        nprof = min(args.steps, 3)
+        for _ in range(nprof):
+            one_step()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        ms, flops, launches = prof.totals()
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_kernel (tmi_gemm: all Dense/Conv1D fwd, dgrad, wgrad GEMMs)",
+                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "launches_per_step": launches / nprof, "gemm_ms_per_step": ms / nprof,
+                "gemm_gflop_per_step": flops / nprof / 1e9,
+                "avg_launch_us": ms * 1e3 / max(1, launches)}
+
+    if rank == 0:
+        gb = args.batch_size * world
+        value = CLIP_SECONDS * gb * args.steps / dt
+        out = {
+            "metric": "audio-seconds/sec/node (Whisper-small, 30 s clips)",
+            "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"whisper-{args.model_type}-ref (reference 'small': 768/12h/3072, 4+4 layers) "
+                                   f"train step, per-GPU batch {args.batch_size}, 30 s clips [80x3000], S=100",
+                       "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
+                       "step_tflops": GF_PER_SAMPLE * gb * args.steps / dt / 1e3 if args.model_type == "small" else None},
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model_type, 3000)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,6 +31,21 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class GemmProfile:
+    """bench.py's roofline probe: HIP events (on the launch stream) around every tmi_gemm
+    launch plus its algorithmic FLOPs (2*M*N*K*nbatch*kbatch)."""
+
+    def __init__(self):
+        self.records = []
+
+    def totals(self):
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
+        return ms, sum(f for _, _, f in self.records), len(self.records)
+
+
+PROFILE = None  # set to a GemmProfile() to instrument
+
+
 def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
          kbatch=1, a_skb=0, b_skb=0, bias=None, scale_cols=0, scale=1.0, accumulate=False,
          act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
@@ -57,7 +72,14 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     d.splitk = splitk
     assert A.dtype == B.dtype
     d.in_dtype, d.out_dtype = dt(A), dt(Cm)
+    if PROFILE is None:
+        check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
+    e1.record()
+    PROFILE.records.append((e0, e1, 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch)))
 
 
 def linear(x2d, w, out, *, w_is_kn=True, **kw):
