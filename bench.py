@@ -46,7 +46,11 @@ def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
     cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     params = O.init_params(cfg, seed=1234, dtype=torch.float32)
     feats, labels = O.create_dummy_pool(seed=1234, seq_len=seq_len, num_samples=sample_batch * (steps + 1))
+    tw = time.time()
     O.train_steps(cfg, params, feats, labels, sample_batch, 1)  # warm-up
+    log(f"cpu baseline warm-up step: {time.time() - tw:.1f} s on {cores} threads")
+    if time.time() - tw > 20.0:
+        steps = 1
     t0 = time.time()
     O.train_steps(cfg, params, feats[sample_batch:], labels[sample_batch:], sample_batch, steps)
     dt = time.time() - t0
@@ -54,6 +58,10 @@ def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
             "kind": "port",
             "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, "
                       f"batch {sample_batch}, {steps} timed steps after 1 warm-up, {dt / steps:.2f} s/step"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -93,8 +101,12 @@ def main():
     def one_step():
         return train.distributed_train_step(strategy, model, next(it), opt)
 
-    for _ in range(args.warmup):
+    log(f"model ready ({model.arena.n_params} params), warming up {args.warmup} steps")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         one_step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     strategy.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -108,6 +120,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     last_loss = float(loss.item())
+    log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step, loss {last_loss:.4f}")
 
     roof = None
     if not args.no_roofline:
@@ -144,6 +157,7 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the restated reference CPU path (oracle) on the host cores")
             out["cpu_baseline"] = cpu_baseline(args.model_type, 3000)
         print(json.dumps(out))
     if world > 1:

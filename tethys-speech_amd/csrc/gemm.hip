@@ -9,6 +9,8 @@
 // along k) or row-contiguous (vector loads along m/n, transposed while written to LDS), so
 // forward (X·W), dgrad (dY·Wᵀ) and wgrad (Xᵀ·dY) all map onto this one kernel.
 #include "tmi_common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -203,41 +205,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     }
   }
 
-  // ---- epilogue ----
-  TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
-  TC* aux_out = d.aux_out ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb : nullptr;
-  const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
-  const TC* resid = d.resid ? reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb : nullptr;
-  const int c = lane & 31, h = lane >> 5;
-  const bool atomic = (nsplit > 1);
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int64_t n = n0 + wc * 64 + ni * 32 + c;
-      if (n >= d.N) continue;
-      const float bv = d.bias ? d.bias[n] : 0.f;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int64_t m = m0 + wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (m >= d.M) continue;
-        const int64_t idx = m * d.ldc + n;
-        float v = acc[mi][ni][reg];
-        if (atomic) {
-          if constexpr (sizeof(TC) == 4) atomicAdd(reinterpret_cast<float*>(C) + idx, v);
-          continue;
-        }
-        v += bv;
-        if (n < d.scale_cols) v *= d.scale;
-        if (d.accumulate) v += to_f32(C[idx]);
-        if (aux_out) aux_out[idx] = from_f32<TC>(v);
-        if (d.act == 1) v = gelu_erf(v);
-        if (aux_in) v *= gelu_erf_grad(to_f32(aux_in[idx]));
-        if (resid) v += to_f32(resid[m * d.r_ld + n]);
-        C[idx] = from_f32<TC>(v);
-      }
-    }
-  }
+  gemm_epilogue<TC>(d, acc, m0, n0, bz, wr, wc, lane, gridDim.y > 1);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -268,6 +236,16 @@ int launch(const tmi_gemm_desc& d, hipStream_t stream) {
 
 }  // namespace
 
+int tmi_gemm_fast_try(const tmi_gemm_desc& d, hipStream_t stream, int* rc);  // gemm_fast.hip
+
+static bool fast_disabled() {
+  static const bool off = [] {
+    const char* e = getenv("TMI_GEMM_GENERIC");
+    return e && e[0] == '1';
+  }();
+  return off;
+}
+
 extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
   if (!dp) return TMI_ERR_INVALID;
   tmi_gemm_desc d = *dp;
@@ -293,6 +271,10 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (d.in_dtype == TMI_BF16 && (d.out_dtype == TMI_BF16 || d.out_dtype == TMI_F32) && !fast_disabled()) {
+    int rc = 0;
+    if (tmi_gemm_fast_try(d, s, &rc)) return rc;
+  }
   if (d.in_dtype == TMI_F32 && d.out_dtype == TMI_F32) return launch<float, float>(d, s);
   if (d.in_dtype == TMI_BF16 && d.out_dtype == TMI_BF16) return launch<bf16_t, bf16_t>(d, s);
   if (d.in_dtype == TMI_BF16 && d.out_dtype == TMI_F32) return launch<bf16_t, float>(d, s);

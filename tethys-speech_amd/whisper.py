@@ -250,24 +250,28 @@ class WhisperForConditionalGeneration:
         self.pe_enc_t = self.pe_enc.to(self.dtype)
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
-        # bf16 shadows (perf mode): one flat buffer, natural [in, out] layout, ld padded to 8
+        # bf16 shadows (perf mode), one flat buffer: the natural Keras [in, out] layout (the
+        # k-contiguous "Bᵀ" operand of dgrad) and its transpose [out, in] (the k-contiguous
+        # operand of forward).  Leading dimensions padded (zeros) to 8 elements; the LM head's
+        # to 64 so its vocab-long reduction in dgrad is a whole number of K tiles.
         self.shadow: Dict[str, torch.Tensor] = {}
-        self.shadow_ld: Dict[str, int] = {}
+        self.shadow_t: Dict[str, torch.Tensor] = {}
         if precision == "bf16":
             total = 0
             plan = []
             for name in self.arena.names:
                 if name.endswith(".kernel"):
                     shape = self.arena.shapes[name]
-                    rows = int(np.prod(shape[:-1]))
-                    ld = _round_up(shape[-1], 8)
-                    plan.append((name, rows, shape[-1], ld, total))
-                    total += rows * ld
+                    rows, cols = int(np.prod(shape[:-1])), shape[-1]
+                    ld = _round_up(cols, 64 if name == "lm_head.kernel" else 8)
+                    ldt = _round_up(rows, 8)
+                    plan.append((name, rows, cols, ld, total, ldt, total + rows * ld))
+                    total += rows * ld + cols * ldt
             self._shadow_buf = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
             self._shadow_plan = plan
-            for name, rows, cols, ld, off in plan:
+            for name, rows, cols, ld, off, ldt, offt in plan:
                 self.shadow[name] = self._shadow_buf[off:off + rows * ld].view(rows, ld)
-                self.shadow_ld[name] = ld
+                self.shadow_t[name] = self._shadow_buf[offt:offt + cols * ldt].view(cols, ldt)
             self.refresh_shadows()
 
     # -- weights ---------------------------------------------------------------------
@@ -275,17 +279,29 @@ class WhisperForConditionalGeneration:
         """bf16 copies of the fp32 master kernels (call after every optimizer step)."""
         if self.precision != "bf16":
             return
-        for name, rows, cols, ld, off in self._shadow_plan:
+        for name, rows, cols, ld, off, ldt, offt in self._shadow_plan:
             ops.cast_bf16(self.arena.p, cols, self._shadow_buf, ld, rows, cols,
                           src_off=self.arena.offsets[name], dst_off=off)
+            ops.transpose_cast_bf16(self.arena.p, cols, self._shadow_buf, ldt, rows, cols,
+                                    src_off=self.arena.offsets[name], dst_off=offt)
 
     def W(self, name) -> Tuple[torch.Tensor, int]:
         """(2-D weight tensor [in, out(+pad)], leading dimension) in the compute dtype."""
         if self.precision == "bf16":
-            return self.shadow[name], self.shadow_ld[name]
+            return self.shadow[name], self.shadow[name].stride(0)
         shape = self.arena.shapes[name]
         rows = int(np.prod(shape[:-1]))
         return self.arena.param(name).view(rows, shape[-1]), shape[-1]
+
+    def _gemm_xw(self, A, wname, Cm, M, N, K, a_sm, *, n_off=0, **kw):
+        """Cm = A · W[:, n_off:n_off+N] with W the [K, N_total] kernel: forward orientation.
+        bf16 reads the transposed shadow (both operands k-contiguous), fp32 the master."""
+        if self.precision == "bf16":
+            wt = self.shadow_t[wname]
+            ops.gemm(A, wt, Cm, M, N, K, a_sm, 1, 1, wt.stride(0), b_off=n_off * wt.stride(0), **kw)
+        else:
+            w, ldw = self.W(wname)
+            ops.gemm(A, w, Cm, M, N, K, a_sm, 1, ldw, 1, b_off=n_off, **kw)
 
     # -- workspaces --------------------------------------------------------------------
     def _buf(self, name, shape, dtype=None, zero=False):
@@ -352,7 +368,7 @@ class WhisperForConditionalGeneration:
         self._buf("dec_out", (Rd, d))
         self._buf("dec_ln.mean", (Rd,), f32)
         self._buf("dec_ln.rstd", (Rd,), f32)
-        self.ldl = _round_up(cfg.vocab_size, 32)
+        self.ldl = _round_up(cfg.vocab_size, 64)
         self._buf("logits", (Rd, self.ldl), **z)
         self._buf("row_loss", (Rd,), f32)
         self._buf("loss", (1,), f32)
@@ -394,8 +410,8 @@ class WhisperForConditionalGeneration:
         bname = wname.replace(".kernel", ".bias")
         if bname in self.arena.offsets:
             bias = self.arena.param(bname)[n_off:n_off + N]
-        ops.gemm(x2d, w, out2d, x2d.shape[0], N, K, x2d.stride(0), 1, ldw, 1, out2d.stride(0),
-                 b_off=n_off, bias=bias, **epi)
+        self._gemm_xw(x2d, wname, out2d, x2d.shape[0], N, K, x2d.stride(0), ldc=out2d.stride(0), n_off=n_off,
+                      bias=bias, **epi)
 
     def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in))."""
@@ -503,13 +519,14 @@ class WhisperForConditionalGeneration:
         # ---- encoder stem (W:329-339)
         xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
         ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
-        w1, ld1 = self.W("encoder.conv1.kernel")
-        ops.gemm(xp0, w1, h1pad, self.T1, d, 3 * Cn, Cn, 1, ld1, 1, d, nbatch=B, a_sb=xp0.stride(0),
-                 c_sb=h1pad.stride(0), c_off=self.pl2 * d, bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
+        self._gemm_xw(xp0, "encoder.conv1.kernel", h1pad, self.T1, d, 3 * Cn, Cn, ldc=d, nbatch=B,
+                      a_sb=xp0.stride(0), c_sb=h1pad.stride(0), c_off=self.pl2 * d,
+                      bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
         w2, ld2 = self.W("encoder.conv2.kernel")
         x = ws["enc0.x_in"] if cfg.encoder_layers else ws["enc_x"]
-        ops.gemm(h1pad, w2, x, T, d, 3 * d, 2 * d, 1, ld2, 1, d, nbatch=B, a_sb=h1pad.stride(0), c_sb=T * d,
-                 bias=a.param("encoder.conv2.bias"), act=1, aux_out=ws["u2"], resid=self.pe_enc_t, r_ld=d, r_sb=0)
+        self._gemm_xw(h1pad, "encoder.conv2.kernel", x, T, d, 3 * d, 2 * d, ldc=d, nbatch=B, a_sb=h1pad.stride(0),
+                      c_sb=T * d, bias=a.param("encoder.conv2.bias"), act=1, aux_out=ws["u2"], resid=self.pe_enc_t,
+                      r_ld=d, r_sb=0)
 
         # ---- encoder layers (W:218-236)
         for i in range(cfg.encoder_layers):
@@ -560,7 +577,7 @@ class WhisperForConditionalGeneration:
         V = cfg.vocab_size
         logits = ws["logits"]
         wl, ldw = self.W("lm_head.kernel")
-        ops.gemm(ws["dec_out"], wl, logits, B * S, V, d, d, 1, ldw, 1, self.ldl)
+        self._gemm_xw(ws["dec_out"], "lm_head.kernel", logits, B * S, V, d, d, ldc=self.ldl)
         gs = loss_scale / (B * (S - 1))
         ops.xent_fwd_bwd(logits, self.ldl, labels, ws["row_loss"], B, S, V, gs)
         ops.sum_scale(ws["row_loss"], ws["loss"], B * S, 1.0 / (B * (S - 1)))
@@ -570,7 +587,10 @@ class WhisperForConditionalGeneration:
         dW = a.grad("lm_head.kernel")
         ops.gemm(ws["dec_out"], logits, dW, d, V, B * S, 1, d, self.ldl, 1, V)
         dtmp = ws["dtmp"][:B * S]
-        ops.gemm(logits, wl, dtmp, B * S, d, V, self.ldl, 1, 1, ldw, d)
+        # dgrad over the vocab: in bf16 the pad columns of dlogits and of the shadow are zero, so
+        # the reduction runs over the padded length (a whole number of K tiles)
+        Kv = self.ldl if self.precision == "bf16" else V
+        ops.gemm(logits, wl, dtmp, B * S, d, Kv, self.ldl, 1, 1, ldw, d)
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
 
         d_enc = ws["d_enc_out"]
