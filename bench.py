@@ -42,6 +42,7 @@ def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)  # the 1-GPU box's CPU share; more threads than share only thrash
     torch.set_num_threads(cores)
     cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     params = O.init_params(cfg, seed=1234, dtype=torch.float32)

@@ -182,11 +182,13 @@ int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stre
  *   eps_mode 0 (TF/Keras-V2): p <- p - lr*sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
  *   eps_mode 1 (torch):       p <- p - lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)
  *   weight_decay (decoupled, AdamW) defaults to 0 in the reference.
- * Algorithmic traffic: 28 B/param (read p,g,m,v; write p,m,v).
+ * bf16_mirror (optional, may be NULL): bf16 copy of the updated parameters, same flat
+ * indexing — the k-contiguous / natural-layout weight operand of the bf16 GEMMs.
+ * Algorithmic traffic: 28 B/param (read p,g,m,v; write p,m,v) + 2 B/param for the mirror.
  */
 int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
-                  float weight_decay, float gscale, void* stream);
+                  float weight_decay, float gscale, void* bf16_mirror, void* stream);
 
 /* bf16 shadows of fp32 master weights: dst[r*ldd + c] = bf16(src[r*lds + c]) and the
  * transposed form dst[c*ldd + r] = bf16(src[r*lds + c]); pad columns [cols, ldd) of the

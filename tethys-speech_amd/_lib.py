@@ -69,14 +69,14 @@ SIGNATURES = {
     "tmi_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "tmi_xent_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_sum_scale": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
-    "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp]),
+    "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),
     "tmi_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_transpose_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_feat_to_channels_last": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_sumsq": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

@@ -24,7 +24,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
                                                    float b2, float eps, float step_size, float vcorr_inv_sqrt,
-                                                   int eps_mode, float decay, float gscale) {
+                                                   int eps_mode, float decay, float gscale,
+                                                   bf16_t* __restrict__ mirror) {
   const int64_t nvec = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
@@ -40,10 +41,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<f32x4*>(p)[i] = pp;
     reinterpret_cast<f32x4*>(m)[i] = mm;
     reinterpret_cast<f32x4*>(v)[i] = vv;
+    if (mirror) {
+      bf16x4 sh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sh[j] = (bf16_t)pp[j];
+      reinterpret_cast<bf16x4*>(mirror)[i] = sh;
+    }
   }
   if (blockIdx.x == 0) {
     const int64_t i = nvec * 4 + threadIdx.x;
-    if (i < n) adam1(p[i], g[i], m[i], v[i], b1, b2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale);
+    if (i < n) {
+      adam1(p[i], g[i], m[i], v[i], b1, b2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale);
+      if (mirror) mirror[i] = (bf16_t)p[i];
+    }
   }
 }
 
@@ -111,9 +121,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 extern "C" int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t step, int32_t eps_mode, float weight_decay,
-                             float gscale, void* stream) {
+                             float gscale, void* bf16_mirror, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0 || (eps_mode != 0 && eps_mode != 1) || !al16(p) || !al16(g) ||
-      !al16(m) || !al16(v)) {
+      !al16(m) || !al16(v) || (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7))) {
     tmi_set_error("tmi_adam_step: bad argument (arenas must be 16-byte aligned, step >= 1)");
     return TMI_ERR_INVALID;
   }
@@ -133,7 +143,8 @@ extern "C" int tmi_adam_step(float* p, const float* g, float* m, float* v, int64
   if (blocks < 1) blocks = 1;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
-                     m, v, n, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale);
+                     m, v, n, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale,
+                     (bf16_t*)bf16_mirror);
   return tmi_check_launch("tmi_adam_step");
 }
 

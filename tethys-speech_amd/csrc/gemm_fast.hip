@@ -1,19 +1,20 @@
-// Fast bf16 GEMM paths of tmi_gemm for the two layouts that carry the step's FLOPs:
-//   NT  C[m][n] = sum_k A[m][k] * Bt[n][k]   both operands k-contiguous
-//       (forward with the transposed weight shadow; dgrad with the natural Keras kernel)
-//   TN  C[i][j] = sum_k A[k][i] * B[k][j]    both operands k-strided
-//       (wgrad: Xᵀ·dY, the reduction index is the activation row)
-// 128x128 output tile per 256-thread workgroup (waves 2x2, 64x64 each, MFMA 32x32x16 bf16),
-// BK = 64.  Operand tiles are staged global -> LDS directly (global_load_lds_dwordx4, no
-// VGPR round trip), double-buffered: the next tile's DMA is in flight under the current
-// tile's MFMAs, one barrier per K-tile.  The LDS image is lane-linear as the DMA requires;
-// the XOR swizzle that makes the fragment reads bank-conflict-free is applied to the per-lane
-// SOURCE address and again on the read (same involution on both sides).
-//   NT image: [128 rows][8 x 16 B chunks];  phys_chunk = chunk ^ ((row >> 1) & 7); fragments
-//             by ds_read_b128.
-//   TN image: [64 k-rows][16 x 16 B chunks]; phys_chunk = chunk ^ ((krow & 3) << 2); fragments
-//             by ds_read_b64_tr_b16 (hardware transpose: a 4(k) x 16(m) block, column-major).
-// Workgroup ids are remapped so that the tiles sharing one A row-panel run on one XCD (L2).
+// Fast bf16 GEMM path of tmi_gemm (gfx950).  One kernel template covers the three layouts
+// that carry the step's FLOPs; each operand is independently
+//   KC  k-contiguous rows   (A[m][k] / Bt[n][k]):  LDS image [128 rows][8 x 16 B], fragments by
+//       ds_read_b128, swizzle phys_chunk = chunk ^ ((row >> 1) & 7)
+//   KS  k-strided           (A[k][m] / B[k][n]):   LDS image [64 k][16 x 16 B], fragments by
+//       ds_read_b64_tr_b16 (hardware transpose of a 4(k) x 16(col) block), swizzle
+//       phys_chunk = chunk ^ ((k & 3) << 2)
+// forward X·W = (KC, KS) straight from the natural Keras [in,out] kernel; dgrad dY·Wᵀ = (KC, KC);
+// wgrad Xᵀ·dY = (KS, KS).  128x128 output tile per 256-thread workgroup (waves 2x2, 64x64 each,
+// MFMA 32x32x16 bf16), BK = 64.  Tiles are staged global -> LDS directly
+// (global_load_lds_dwordx4), double-buffered: the next tile's DMA is in flight under the
+// current tile's MFMAs, one barrier per K-tile.  The LDS image is lane-linear as the DMA
+// requires; the swizzle is applied to the per-lane SOURCE address and again on the read.
+// Epilogue: accumulators go through LDS (fp32, per-wave 64x64) and leave as whole 16-byte
+// row segments — bias/scale/accumulate/GELU/GELU'/residual are applied on 8-column chunks
+// with 16-byte loads and stores (a 2-byte-per-lane store tail is store-issue-bound).
+// Workgroup ids are remapped so that tiles sharing one A row-panel run on one XCD (L2).
 #include "tmi_common.h"
 #include "gemm_epilogue.h"
 
@@ -31,6 +32,9 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 struct FastParams {
   tmi_gemm_desc d;
   int tiles_m, tiles_n, ktiles;
+  int wide;          // epilogue may use 16-byte accesses on C / aux / resid
+  int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
+  int64_t b_cols_rd;
 };
 
 // bijective XCD-aware remap: consecutive new ids share an XCD
@@ -39,8 +43,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// ---- NT staging: 128 rows x 64 k (128 B per row)
-__device__ __forceinline__ void stage_nt(char* lds, const bf16_t* base, int64_t s_row, int64_t row0, int64_t nrows,
+// ---- KC staging: 128 rows x 64 k (128 B per row)
+__device__ __forceinline__ void stage_kc(char* lds, const bf16_t* base, int64_t s_row, int64_t row0, int64_t nrows,
                                          int64_t k0, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -53,28 +57,8 @@ __device__ __forceinline__ void stage_nt(char* lds, const bf16_t* base, int64_t 
   }
 }
 
-__device__ __forceinline__ void mma_nt(const char* As, const char* Bs, int wr, int wc, int lane, f32x16 (&acc)[2][2]) {
-  const int r = lane & 31, h = lane >> 5;
-  const int sw = (r >> 1) & 7;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], b[2];
-    const int off = ((2 * kk + h) ^ sw) * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      a[i] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + i * 32 + r) * 128 + off);
-      b[i] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + i * 32 + r) * 128 + off);
-    }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-  }
-}
-
-// ---- TN staging: 64 k-rows x 128 cols (256 B per row)
-__device__ __forceinline__ void stage_tn(char* lds, const bf16_t* base, int64_t s_k, int64_t col0, int64_t ncols,
+// ---- KS staging: 64 k-rows x 128 cols (256 B per row)
+__device__ __forceinline__ void stage_ks(char* lds, const bf16_t* base, int64_t s_k, int64_t col0, int64_t ncols_rd,
                                          int64_t k0, int64_t kend, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -84,12 +68,17 @@ __device__ __forceinline__ void stage_tn(char* lds, const bf16_t* base, int64_t 
     int64_t gk = k0 + kr;
     gk = gk < kend ? gk : kend - 1;
     int64_t gc = col0 + c * 8;
-    gc = gc + 8 <= ncols ? gc : ncols - 8;
+    gc = gc + 8 <= ncols_rd ? gc : ncols_rd - 8;
     glds16(base + gk * s_k + gc, lds + j * 1024);
   }
 }
 
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col_base, int kk, int lane) {
+__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int row, int kk, int h) {
+  const int off = ((2 * kk + h) ^ ((row >> 1) & 7)) * 16;
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + off);
+}
+
+__device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk, int lane) {
   // 32x32x16 operand fragment for k-step kk from a [k][col] image: lane (r, h) gets
   // T[16kk + 8h + j][col_base + r], j = 0..7, as two transposed 4x16 block reads.
   const int g = lane >> 4, i = lane & 15;
@@ -107,14 +96,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int col_base, int kk
   return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__device__ __forceinline__ void mma_tn(const char* As, const char* Bs, int wr, int wc, int lane, f32x16 (&acc)[2][2]) {
+template <bool A_KS, bool B_KS>
+__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wr, int wc, int lane,
+                                         f32x16 (&acc)[2][2]) {
+  const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
     bf16x8 a[2], b[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      a[i] = tr_frag(As, wr * 64 + i * 32, kk, lane);
-      b[i] = tr_frag(Bs, wc * 64 + i * 32, kk, lane);
+      if constexpr (A_KS) a[i] = frag_ks(As, wr * 64 + i * 32, kk, lane);
+      else a[i] = frag_kc(As, wr * 64 + i * 32 + r, kk, h);
+      if constexpr (B_KS) b[i] = frag_ks(Bs, wc * 64 + i * 32, kk, lane);
+      else b[i] = frag_kc(Bs, wc * 64 + i * 32 + r, kk, h);
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -124,7 +118,135 @@ __device__ __forceinline__ void mma_tn(const char* As, const char* Bs, int wr, i
   }
 }
 
-template <typename TC, bool TN>
+// ---- wide epilogue helpers
+template <typename TC> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+};
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+  }
+};
+
+__device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((col * 4) ^ ((row & 1) << 4)); }
+
+template <typename TC>
+__device__ __forceinline__ void wide_epilogue(const FastParams& P, f32x16 (&acc)[2][2], char* smem, int64_t m0,
+                                              int64_t n0, int64_t bz, int wave, int lane, bool atomic) {
+  const tmi_gemm_desc& d = P.d;
+  const int wr = wave >> 1, wc = wave & 1;
+  char* E = smem + wave * 16384;  // this wave's 64x64 fp32 image
+  {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int row = mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+          *reinterpret_cast<float*>(E + epi_off(row, ni * 32 + c)) = acc[mi][ni][reg];
+        }
+  }
+  TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
+  if (atomic) {  // split-K: fp32 atomics, 256 contiguous bytes per wave-instruction
+    if constexpr (sizeof(TC) == 4) {
+      const int64_t n = n0 + wc * 64 + lane;
+      if (n < d.N) {
+        for (int row = 0; row < 64; ++row) {
+          const int64_t m = m0 + wr * 64 + row;
+          if (m >= d.M) break;
+          atomicAdd(reinterpret_cast<float*>(C) + m * d.ldc + n, *reinterpret_cast<const float*>(E + epi_off(row, lane)));
+        }
+      }
+    }
+    return;
+  }
+  TC* aux_out = d.aux_out ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb : nullptr;
+  const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
+  const TC* resid = d.resid ? reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb : nullptr;
+  const int chunk = lane & 7;
+  const int64_t n = n0 + wc * 64 + chunk * 8;
+  if (n >= d.N) return;
+  const bool full = P.wide && (n + 8 <= d.N);
+  float bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[n + i] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = p * 8 + (lane >> 3);
+    const int64_t m = m0 + wr * 64 + row;
+    if (m >= d.M) continue;
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(E + epi_off(row, chunk * 8));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(E + epi_off(row, chunk * 8 + 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    const int64_t idx = m * d.ldc + n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] += bv[i];
+      if (n + i < d.scale_cols) v[i] *= d.scale;
+    }
+    if (full) {
+      float t[8];
+      if (d.accumulate) {
+        Vec8<TC>::load(C + idx, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+      }
+      if (aux_out) Vec8<TC>::store(aux_out + idx, v);
+      if (d.act == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+      }
+      if (aux_in) {
+        Vec8<TC>::load(aux_in + idx, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf_grad(t[i]);
+      }
+      if (resid) {
+        Vec8<TC>::load(resid + m * d.r_ld + n, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+      }
+      Vec8<TC>::store(C + idx, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (n + i >= d.N) break;
+        float x = v[i];
+        if (d.accumulate) x += to_f32(C[idx + i]);
+        if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
+        if (d.act == 1) x = gelu_erf(x);
+        if (aux_in) x *= gelu_erf_grad(to_f32(aux_in[idx + i]));
+        if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
+        C[idx + i] = from_f32<TC>(x);
+      }
+    }
+  }
+}
+
+template <typename TC, bool A_KS, bool B_KS>
 __global__ __launch_bounds__(256) void gemm_fast_kernel(const FastParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
   const tmi_gemm_desc& d = P.d;
@@ -155,28 +277,26 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const FastParams P) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   auto stage = [&](int it, int buf) {
-    const int kb = it / P.ktiles, kt = it % P.ktiles;
+    const int kb = it / P.ktiles, kt = it - kb * P.ktiles;
     char* As = smem + buf * 2 * FT_BYTES;
     char* Bs = As + FT_BYTES;
-    if constexpr (TN) {
-      stage_tn(As, Abase + kb * d.a_skb, d.a_sk, m0, d.M, (int64_t)kt * 64, d.K, wave, lane);
-      stage_tn(Bs, Bbase + kb * d.b_skb, d.b_sk, n0, d.N, (int64_t)kt * 64, d.K, wave, lane);
-    } else {
-      stage_nt(As, Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane);
-      stage_nt(Bs, Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane);
-    }
+    if constexpr (A_KS) stage_ks(As, Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
+    else stage_kc(As, Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane);
+    if constexpr (B_KS) stage_ks(Bs, Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
+    else stage_kc(Bs, Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane);
   };
-  // TN only: rows k >= K of the last tile were loaded from a clamped row; zero them
+  // K tail (K % 64 != 0, host allows it only when an operand is KS): rows k >= K of a KS image
+  // were loaded from a clamped row; zero them so they contribute nothing
   auto zero_tail = [&](int it, int buf) {
-    if constexpr (TN) {
+    if constexpr (A_KS || B_KS) {
       const int kt = it % P.ktiles;
       const int kvalid = (int)min((int64_t)64, d.K - (int64_t)kt * 64);
       if (kvalid < 64) {
         char* As = smem + buf * 2 * FT_BYTES;
         for (int idx = threadIdx.x; idx < (64 - kvalid) * 16; idx += 256) {
           const int off = kvalid * 256 + idx * 16;
-          *reinterpret_cast<u32x4*>(As + off) = u32x4{0u, 0u, 0u, 0u};
-          *reinterpret_cast<u32x4*>(As + FT_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
+          if constexpr (A_KS) *reinterpret_cast<u32x4*>(As + off) = u32x4{0u, 0u, 0u, 0u};
+          if constexpr (B_KS) *reinterpret_cast<u32x4*>(As + FT_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
       }
@@ -193,50 +313,60 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const FastParams P) {
       zero_tail(it, cur);
       const char* As = smem + cur * 2 * FT_BYTES;
       const char* Bs = As + FT_BYTES;
-      if constexpr (TN)
-        mma_tn(As, Bs, wr, wc, lane, acc);
-      else
-        mma_nt(As, Bs, wr, wc, lane, acc);
+      mma_tile<A_KS, B_KS>(As, Bs, wr, wc, lane, acc);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       cur ^= 1;
     }
   }
-  gemm_epilogue<TC>(d, acc, m0, n0, bz, wr, wc, lane, nsplit > 1);
+  wide_epilogue<TC>(P, acc, smem, m0, n0, bz, wave, lane, nsplit > 1);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int64_t rup8(int64_t x) { return (x + 7) / 8 * 8; }
 
-template <typename TC, bool TN>
+template <typename TC, bool A_KS, bool B_KS>
 int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   FastParams P;
   P.d = d;
   P.tiles_m = (int)((d.M + 127) / 128);
   P.tiles_n = (int)((d.N + 127) / 128);
   P.ktiles = (int)((d.K + 63) / 64);
+  P.a_cols_rd = rup8(d.M);
+  P.b_cols_rd = rup8(d.N);
+  const int vecC = 16 / (int)sizeof(TC);
+  P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
+           (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   const int splitk = d.splitk > 1 ? d.splitk : 1;
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)d.nbatch);
-  hipLaunchKernelGGL((gemm_fast_kernel<TC, TN>), grid, dim3(256), 4 * FT_BYTES, stream, P);
+  hipLaunchKernelGGL((gemm_fast_kernel<TC, A_KS, B_KS>), grid, dim3(256), 4 * FT_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm(fast)");
+}
+
+template <bool A_KS, bool B_KS>
+int launch_out(const tmi_gemm_desc& d, hipStream_t stream) {
+  return d.out_dtype == TMI_F32 ? launch_fast<float, A_KS, B_KS>(d, stream) : launch_fast<bf16_t, A_KS, B_KS>(d, stream);
 }
 
 }  // namespace
 
-// Returns 1 and sets *rc if a fast path took the GEMM, 0 if the generic kernel must run.
+// Returns 1 and sets *rc if the fast path took the GEMM, 0 if the generic kernel must run.
 int tmi_gemm_fast_try(const tmi_gemm_desc& d, hipStream_t stream, int* rc) {
   if (d.in_dtype != TMI_BF16) return 0;
   if (!al16(d.A) || !al16(d.B) || d.a_sb % 8 || d.b_sb % 8 || d.a_skb % 8 || d.b_skb % 8) return 0;
-  const bool f32out = d.out_dtype == TMI_F32;
-  // NT: both k-contiguous, K a multiple of the 64-wide tile, rows 16-byte aligned
-  if (d.a_sk == 1 && d.b_sk == 1 && d.K % 64 == 0 && d.a_sm % 8 == 0 && d.b_sn % 8 == 0) {
-    *rc = f32out ? launch_fast<float, false>(d, stream) : launch_fast<bf16_t, false>(d, stream);
-    return 1;
-  }
-  // TN: both k-strided with contiguous columns; whole 16-byte column chunks
-  if (d.a_sm == 1 && d.b_sn == 1 && d.a_sk % 8 == 0 && d.b_sk % 8 == 0 && d.M % 8 == 0 && d.N % 8 == 0 &&
-      d.M >= 8 && d.N >= 8) {
-    *rc = f32out ? launch_fast<float, true>(d, stream) : launch_fast<bf16_t, true>(d, stream);
-    return 1;
-  }
-  return 0;
+  // operand modes: KC = k-contiguous rows (16-byte aligned row starts), KS = k-strided with
+  // contiguous columns whose 16-byte chunks are all readable (row stride >= round_up(cols, 8))
+  const bool a_kc = d.a_sk == 1 && d.a_sm % 8 == 0;
+  const bool b_kc = d.b_sk == 1 && d.b_sn % 8 == 0;
+  const bool a_ks = d.a_sm == 1 && d.a_sk % 8 == 0 && d.a_sk >= rup8(d.M) && d.M >= 8;
+  const bool b_ks = d.b_sn == 1 && d.b_sk % 8 == 0 && d.b_sk >= rup8(d.N) && d.N >= 8;
+  if (!(a_kc || a_ks) || !(b_kc || b_ks)) return 0;
+  const bool A_KS = !a_kc, B_KS = !b_kc;
+  // a KC image cannot mask a partial K tile (its DMA would read past the row): K tails only in (KS, KS)
+  if (d.K % 64 != 0 && (!A_KS || !B_KS)) return 0;
+  if (A_KS && B_KS) *rc = launch_out<true, true>(d, stream);
+  else if (A_KS) *rc = launch_out<true, false>(d, stream);
+  else if (B_KS) *rc = launch_out<false, true>(d, stream);
+  else *rc = launch_out<false, false>(d, stream);
+  return 1;
 }

@@ -162,13 +162,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t P,
-                                   int64_t N, int accumulate) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// 64 columns per block, 4 partial-row lanes per column, folded through LDS in a fixed order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int64_t P, int64_t N, int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int64_t p = 0; p < P; ++p) s += part[p * N + n];
-  out[n] = accumulate ? out[n] + s : s;
+  if (n < N)
+    for (int64_t p = pg; p < P; p += 4) s += part[p * N + n];
+  red[pg][c] = s;
+  __syncthreads();
+  if (pg == 0 && n < N) {
+    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[n] = accumulate ? out[n] + t : t;
+  }
 }
 
 template <typename T>
@@ -275,7 +283,7 @@ extern "C" int tmi_reduce_rows(const float* part, float* out, int64_t P, int64_t
     tmi_set_error("tmi_reduce_rows: bad argument");
     return TMI_ERR_INVALID;
   }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), part, out, P, N, accumulate);
   return tmi_check_launch("tmi_reduce_rows");
 }

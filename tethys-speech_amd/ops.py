@@ -192,9 +192,9 @@ def sum_scale(x, out, n, scale):
     check(lib().tmi_sum_scale(x.data_ptr(), out.data_ptr(), n, scale, stream()), "tmi_sum_scale")
 
 
-def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0):
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0, mirror=None):
     check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
-                              eps, step, eps_mode, weight_decay, gscale, stream()), "tmi_adam_step")
+                              eps, step, eps_mode, weight_decay, gscale, ptr(mirror), stream()), "tmi_adam_step")
 
 
 def cast_bf16(src, lds, dst, ldd, rows, cols, src_off=0, dst_off=0):

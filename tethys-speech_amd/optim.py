@@ -4,7 +4,7 @@ One kernel launch for the whole model (``tmi_adam_step``): Keras-V2 epsilon plac
 default (``eps_mode="tf"``), AdamW-style decoupled weight decay available but 0 as in the
 reference.  ``apply_gradients`` is the analogue of ``optimizer.apply_gradients`` (W:834):
 it first lets the strategy all-reduce the gradient arena (the implicit cross-replica SUM
-of Keras OptimizerV2), then updates, then refreshes the model's bf16 weight shadows.
+of Keras OptimizerV2), then updates; the same kernel writes the model's bf16 weight mirror.
 """
 from __future__ import annotations
 
@@ -28,5 +28,4 @@ class Adam:
             strategy.all_reduce_gradients(a.g)
         self.iterations += 1
         ops.adam_step(a.p, a.g, a.m, a.v, a.numel, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
-                      self.iterations, self.eps_mode, self.weight_decay, grad_scale)
-        model.refresh_shadows()
+                      self.iterations, self.eps_mode, self.weight_decay, grad_scale, mirror=model.mirror)

@@ -141,7 +141,12 @@ class ParamArena:
             ln(f"{p}.final_layer_norm")
             ffn(f"{p}.feed_forward")
         ln("decoder.layer_norm")
-        spec.append(("lm_head.kernel", (d, V)))
+        # the LM head is STORED with its vocab axis padded to a multiple of 64 (zero columns that
+        # stay zero under Adam: g = 0 => m = v = 0 => no update), so logits / dlogits rows are
+        # 16-byte aligned and the vocab-long reductions are whole K tiles; logical shape (d, V)
+        self.v_pad = _round_up(V, 64)
+        spec.append(("lm_head.kernel", (d, self.v_pad)))
+        self.logical: Dict[str, Tuple[int, ...]] = {"lm_head.kernel": (d, V)}
 
         self.offsets: Dict[str, int] = {}
         self.shapes: Dict[str, Tuple[int, ...]] = {}
@@ -149,9 +154,9 @@ class ParamArena:
         for name, shape in spec:
             self.offsets[name] = off
             self.shapes[name] = shape
-            off += _round_up(int(np.prod(shape)), 4)  # keep every tensor 16-byte aligned
+            off += _round_up(int(np.prod(shape)), 8)  # 16-byte alignment in the bf16 mirror too
         self.numel = off
-        self.n_params = sum(int(np.prod(s)) for s in self.shapes.values())
+        self.n_params = sum(int(np.prod(self.logical.get(n, s))) for n, s in self.shapes.items())
         self.p = torch.zeros(off, dtype=torch.float32, device=device)
         self.g = torch.zeros_like(self.p)
         self.m = torch.zeros_like(self.p)
@@ -190,6 +195,8 @@ class ParamArena:
                 base = name[:-len("kv.bias")]
                 for j, n in enumerate(("k_proj", "v_proj")):
                     out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
+            elif name in self.logical:
+                out[name] = t[tuple(slice(0, n) for n in self.logical[name])]
             else:
                 out[name] = t
         return out
@@ -250,58 +257,34 @@ class WhisperForConditionalGeneration:
         self.pe_enc_t = self.pe_enc.to(self.dtype)
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
-        # bf16 shadows (perf mode), one flat buffer: the natural Keras [in, out] layout (the
-        # k-contiguous "Bᵀ" operand of dgrad) and its transpose [out, in] (the k-contiguous
-        # operand of forward).  Leading dimensions padded (zeros) to 8 elements; the LM head's
-        # to 64 so its vocab-long reduction in dgrad is a whole number of K tiles.
-        self.shadow: Dict[str, torch.Tensor] = {}
-        self.shadow_t: Dict[str, torch.Tensor] = {}
+        # bf16 mirror of the whole parameter arena (perf mode), same flat indexing: every
+        # kernel in its natural Keras [in, out] layout.  Forward reads it k-strided (hardware
+        # transposed LDS reads), dgrad reads it k-contiguous.  Written by the Adam kernel itself.
+        self.mirror = None
         if precision == "bf16":
-            total = 0
-            plan = []
-            for name in self.arena.names:
-                if name.endswith(".kernel"):
-                    shape = self.arena.shapes[name]
-                    rows, cols = int(np.prod(shape[:-1])), shape[-1]
-                    ld = _round_up(cols, 64 if name == "lm_head.kernel" else 8)
-                    ldt = _round_up(rows, 8)
-                    plan.append((name, rows, cols, ld, total, ldt, total + rows * ld))
-                    total += rows * ld + cols * ldt
-            self._shadow_buf = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
-            self._shadow_plan = plan
-            for name, rows, cols, ld, off, ldt, offt in plan:
-                self.shadow[name] = self._shadow_buf[off:off + rows * ld].view(rows, ld)
-                self.shadow_t[name] = self._shadow_buf[offt:offt + cols * ldt].view(cols, ldt)
+            self.mirror = torch.zeros(self.arena.numel, dtype=torch.bfloat16, device=self.device)
             self.refresh_shadows()
 
     # -- weights ---------------------------------------------------------------------
     def refresh_shadows(self):
-        """bf16 copies of the fp32 master kernels (call after every optimizer step)."""
+        """Re-derive the bf16 mirror from the fp32 master (after loading weights; the optimizer
+        step keeps it current by itself)."""
         if self.precision != "bf16":
             return
-        for name, rows, cols, ld, off, ldt, offt in self._shadow_plan:
-            ops.cast_bf16(self.arena.p, cols, self._shadow_buf, ld, rows, cols,
-                          src_off=self.arena.offsets[name], dst_off=off)
-            ops.transpose_cast_bf16(self.arena.p, cols, self._shadow_buf, ldt, rows, cols,
-                                    src_off=self.arena.offsets[name], dst_off=offt)
+        n = self.arena.numel
+        ops.cast_bf16(self.arena.p, n, self.mirror, n, 1, n)
 
     def W(self, name) -> Tuple[torch.Tensor, int]:
-        """(2-D weight tensor [in, out(+pad)], leading dimension) in the compute dtype."""
-        if self.precision == "bf16":
-            return self.shadow[name], self.shadow[name].stride(0)
+        """(2-D weight tensor [in, out], leading dimension) in the compute dtype."""
         shape = self.arena.shapes[name]
         rows = int(np.prod(shape[:-1]))
-        return self.arena.param(name).view(rows, shape[-1]), shape[-1]
+        buf = self.mirror if self.precision == "bf16" else self.arena.p
+        return self.arena.view(buf, name).view(rows, shape[-1]), shape[-1]
 
     def _gemm_xw(self, A, wname, Cm, M, N, K, a_sm, *, n_off=0, **kw):
-        """Cm = A · W[:, n_off:n_off+N] with W the [K, N_total] kernel: forward orientation.
-        bf16 reads the transposed shadow (both operands k-contiguous), fp32 the master."""
-        if self.precision == "bf16":
-            wt = self.shadow_t[wname]
-            ops.gemm(A, wt, Cm, M, N, K, a_sm, 1, 1, wt.stride(0), b_off=n_off * wt.stride(0), **kw)
-        else:
-            w, ldw = self.W(wname)
-            ops.gemm(A, w, Cm, M, N, K, a_sm, 1, ldw, 1, b_off=n_off, **kw)
+        """Cm = A · W[:, n_off:n_off+N] with W the natural [K, N_total] kernel (forward)."""
+        w, ldw = self.W(wname)
+        ops.gemm(A, w, Cm, M, N, K, a_sm, 1, ldw, 1, b_off=n_off, **kw)
 
     # -- workspaces --------------------------------------------------------------------
     def _buf(self, name, shape, dtype=None, zero=False):
@@ -368,7 +351,7 @@ class WhisperForConditionalGeneration:
         self._buf("dec_out", (Rd, d))
         self._buf("dec_ln.mean", (Rd,), f32)
         self._buf("dec_ln.rstd", (Rd,), f32)
-        self.ldl = _round_up(cfg.vocab_size, 64)
+        self.ldl = self.arena.v_pad
         self._buf("logits", (Rd, self.ldl), **z)
         self._buf("row_loss", (Rd,), f32)
         self._buf("loss", (1,), f32)
@@ -577,7 +560,8 @@ class WhisperForConditionalGeneration:
         V = cfg.vocab_size
         logits = ws["logits"]
         wl, ldw = self.W("lm_head.kernel")
-        self._gemm_xw(ws["dec_out"], "lm_head.kernel", logits, B * S, V, d, d, ldc=self.ldl)
+        Vp = self.ldl  # pad columns of the stored kernel are zero: their logits are 0 and ignored by xent
+        self._gemm_xw(ws["dec_out"], "lm_head.kernel", logits, B * S, Vp, d, d, ldc=Vp)
         gs = loss_scale / (B * (S - 1))
         ops.xent_fwd_bwd(logits, self.ldl, labels, ws["row_loss"], B, S, V, gs)
         ops.sum_scale(ws["row_loss"], ws["loss"], B * S, 1.0 / (B * (S - 1)))
@@ -585,12 +569,10 @@ class WhisperForConditionalGeneration:
         # ================= backward =================
         dres = ws["dres_dec"]
         dW = a.grad("lm_head.kernel")
-        ops.gemm(ws["dec_out"], logits, dW, d, V, B * S, 1, d, self.ldl, 1, V)
+        ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp)
         dtmp = ws["dtmp"][:B * S]
-        # dgrad over the vocab: in bf16 the pad columns of dlogits and of the shadow are zero, so
-        # the reduction runs over the padded length (a whole number of K tiles)
-        Kv = self.ldl if self.precision == "bf16" else V
-        ops.gemm(logits, wl, dtmp, B * S, d, Kv, self.ldl, 1, 1, ldw, d)
+        # dgrad over the padded vocab (pad columns of dlogits are zero): a whole number of K tiles
+        ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
 
         d_enc = ws["d_enc_out"]
