@@ -31,8 +31,8 @@ __device__ __forceinline__ void gemm_epilogue(const tmi_gemm_desc& d, f32x16 (&a
         if (n < d.scale_cols) v *= d.scale;
         if (d.accumulate) v += to_f32(C[idx]);
         if (aux_out) aux_out[idx] = from_f32<TC>(v);
-        if (d.act == 1) v = gelu_erf(v);
-        if (aux_in) v *= gelu_erf_grad(to_f32(aux_in[idx]));
+        if (d.act == 1) v = gelu_fwd_t<TC>(v);
+        if (aux_in) v *= gelu_grad_t<TC>(to_f32(aux_in[idx]));
         if (resid) v += to_f32(resid[m * d.r_ld + n]);
         C[idx] = from_f32<TC>(v);
       }

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy,
     const T* eb = reinterpret_cast<const T*>(&b);
     alignas(16) T o[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = from_f32<T>(to_f32(ea[j]) * gelu_erf_grad(to_f32(eb[j])));
+    for (int j = 0; j < VEC; ++j) o[j] = from_f32<T>(to_f32(ea[j]) * gelu_grad_t<T>(to_f32(eb[j])));
     reinterpret_cast<u32x4*>(dx)[i] = *reinterpret_cast<const u32x4*>(o);
   }
 }

@@ -38,6 +38,35 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// bf16-output variants: Abramowitz-Stegun 7.1.26 erf (|abs err| <= 1.5e-7, far below a bf16
+// ulp) — 1 rcp + 1 exp + 6 fma instead of erff's ~60 instructions, so the GELU epilogue of
+// the FFN GEMMs stays under the store time.  cdf and pdf share the one exponential.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);  // = exp(-x^2/2)
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float erf_abs = 1.0f - p * t * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143267794f * e;
+}
+template <typename TC> __device__ __forceinline__ float gelu_fwd_t(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_fwd_t<bf16_t>(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return x * c;
+}
+template <typename TC> __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return c + x * p;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
