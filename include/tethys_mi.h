@@ -83,27 +83,20 @@ int tmi_gemm(const tmi_gemm_desc* d, void* stream);
  * LayerNorm over the last axis of x[rows, C].  Replaces
  * tf.keras.layers.LayerNormalization(epsilon=1e-5) (W:214,216,245,249,253,322,392) and
  * its gradient.  mean/rstd are fp32 [rows], saved for backward.
- * Backward: dgamma/dbeta are produced as `nparts` fp32 partial rows in part[2*nparts*C]
- * (first nparts*C = dgamma partials, then dbeta) and must be folded by tmi_reduce_rows;
- * nparts = tmi_layernorm_bwd_parts(rows).
+ * Backward: dgamma[C] / dbeta[C] are ACCUMULATED (fp32 atomics, one per column per
+ * workgroup) — the caller zeroes them; dx = (accumulate_dx ? dx : 0) + dLN/dx.
  */
 int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                       float* mean, float* rstd, int64_t rows, int64_t C, float eps,
                       int32_t dtype, void* stream);
-int64_t tmi_layernorm_bwd_parts(int64_t rows);
 int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                      const float* rstd, void* dx, float* part, int64_t rows, int64_t C,
-                      int32_t accumulate_dx, int32_t dtype, void* stream);
+                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
+                      int64_t C, int32_t accumulate_dx, int32_t dtype, void* stream);
 
-/* out[n] (+)= sum_{p<P} part[p*N + n].  Deterministic second stage for the bias /
- * gamma / beta gradients.  */
-int tmi_reduce_rows(const float* part, float* out, int64_t P, int64_t N, int32_t accumulate,
-                    void* stream);
-
-/* Column sums of dY[rows, N] (the bias gradient of a Dense / Conv1D layer).  Writes
- * nparts = tmi_colsum_parts(rows) fp32 partial rows to part[nparts*N]. */
-int64_t tmi_colsum_parts(int64_t rows);
-int tmi_colsum(const void* dy, int64_t ld, float* part, int64_t rows, int64_t N,
+/* out[n] += sum over rows of dY[rows, N] (row stride ld): the bias gradient of a Dense /
+ * Conv1D layer.  Accumulates with fp32 atomics (one per column per workgroup); the caller
+ * zeroes `out`. */
+int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N,
                int32_t dtype, void* stream);
 
 /* dx = dy * gelu_erf'(u), elementwise over n elements (backward of W:336 where the GELU

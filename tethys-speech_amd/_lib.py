@@ -55,10 +55,7 @@ SIGNATURES = {
     "tmi_last_error": (C.c_char_p, []),
     "tmi_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "tmi_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
-    "tmi_layernorm_bwd_parts": (c_i64, [c_i64]),
-    "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
-    "tmi_reduce_rows": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp]),
-    "tmi_colsum_parts": (c_i64, [c_i64]),
+    "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "tmi_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "tmi_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "tmi_softmax_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
@@ -76,7 +73,7 @@ SIGNATURES = {
     "tmi_sumsq": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

@@ -2,17 +2,22 @@
 // Replaces speech_jobs/whisper_dist.py:147-171 (q·kᵀ, additive mask, softmax, probs·v, head
 // merge) and its gradient without materialising the [B,H,Tq,Tk] score tensor.
 //
-// One template serves forward, the dQ pass and the dK/dV pass:
+// One structure serves forward, the dQ pass and the dK/dV pass:
 //   - a wavefront OWNS 32 rows (queries in fwd/dQ, keys in dK/dV); the owner index sits on
 //     the MFMA lane, its 64-wide vectors live in registers as B operands;
-//   - the other ("streamed") index is walked in 32-row tiles staged through LDS once per
-//     workgroup (4 waves = 128 owners share each tile), in natural [row][d] form for the
-//     "first" products (X[s][o] = sum_d T[s][d]·Own[o][d]) and in transposed [d][row] form
-//     for the "second" products (Yᵀ[d][o] += sum_s T[s][d]·X[s][o]);
+//   - the other ("streamed") index is walked in 64-row tiles that the workgroup (4 waves =
+//     128 owners) stages ONCE, global -> LDS by DMA (global_load_lds_dwordx4), double-buffered
+//     so the next tile is in flight under the current tile's MFMAs;
+//   - ONE natural [row][64 d] LDS image per tile serves both products: row fragments by
+//     ds_read_b128 for X[s][o] = sum_d T[s][d]·Own[o][d], and hardware-transposed fragments by
+//     ds_read_b64_tr_b16 for Yᵀ[d][o] += sum_s T[s][d]·X[s][o].  The 16-byte chunk swizzle
+//     phys = chunk ^ (((row >> 1) & 1) << 2 | ((row >> 2) & 3)) makes both read kinds
+//     bank-conflict-free; it is applied to the DMA's per-lane source address and on the reads;
 //   - X (scores / probabilities / dS) never leaves the accumulator registers: a 32x32 MFMA
 //     result has its column on the lane and its rows in the registers, so it is directly the
-//     B operand of the next MFMA that sums over its rows (k-order inside a step permuted:
-//     element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3));
+//     B operand of the next MFMA that sums over its rows (k-order inside a 16-step permuted:
+//     element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3); the transposed reads fetch
+//     the other operand in that same order);
 //   - softmax statistics are per-lane scalars in fwd/dQ (query on the lane) and per-row
 //     constants from LDS in dK/dV.
 // The reference's decoder mask (W:416-418 + W:152-153) adds -1e9 in fp32 to keys j <= i;
@@ -23,34 +28,37 @@
 namespace {
 
 constexpr int HD = 64;
-constexpr int TN_STRIDE = 144;  // natural tile: 32 rows x (128 B + 16 pad)
-constexpr int TT_STRIDE = 80;   // transposed tile: 64 rows (d) x (64 B + 16 pad)
-constexpr int TN_BYTES = 32 * TN_STRIDE;
-constexpr int TT_BYTES = 64 * TT_STRIDE;
+constexpr int TROWS = 64;             // streamed rows per tile
+constexpr int IMG = TROWS * 128;      // bytes of one [64][64] bf16 image
 
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
 
-__device__ __forceinline__ void tile_fetch(u32x4& reg, const bf16_t* base, int64_t st, int row0, int T) {
-  const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
-  const int gr = row0 + row;
-  if (gr < T) {
-    reg = *reinterpret_cast<const u32x4*>(base + (int64_t)gr * st + ch * 8);
-  } else {
-    reg = u32x4{0u, 0u, 0u, 0u};
+// LDS-DMA from inline asm (see gemm_fast.hip: keeps hipcc from draining it before LDS reads)
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_wave_base);
+  const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(dst_u)
+               : "memory");
+}
+
+// stage rows [row0, row0+64) of a [T][.. 64 d ..] matrix (token stride st elements) into img
+__device__ __forceinline__ void stage_img(char* img, const bf16_t* base, int64_t st, int row0, int T, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = 2 * wave + i;
+    const int r = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    int gr = row0 + r;
+    gr = gr < T ? gr : T - 1;
+    glds16(base + (int64_t)gr * st + c * 8, img + j * 1024);
   }
 }
-__device__ __forceinline__ void tile_commit_nat(char* Tn, const u32x4& reg) {
-  const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
-  *reinterpret_cast<u32x4*>(Tn + row * TN_STRIDE + ch * 16) = reg;
-}
-__device__ __forceinline__ void tile_commit_tr(char* Tt, const u32x4& reg) {
-  const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
-  const bf16_t* e = reinterpret_cast<const bf16_t*>(&reg);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<bf16_t*>(Tt + (ch * 8 + j) * TT_STRIDE + row * 2) = e[j];
-}
 
-// owner vectors: lane (c, h) holds Own[o0 + c][16kk + 8h .. +7], kk = 0..3
+// owner vectors: lane (c, h) holds Own[o][16kk + 8h .. +7], kk = 0..3
 __device__ __forceinline__ void load_owner(bf16x8 (&f)[4], const bf16_t* base, int64_t st, int o, int T, int h) {
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -63,21 +71,25 @@ __device__ __forceinline__ void load_owner(bf16x8 (&f)[4], const bf16_t* base, i
   }
 }
 
-// X[s][o] = sum_d Tn[s][d] * Own[o][d]
-__device__ __forceinline__ f32x16 first_product(const char* Tn, const bf16x8 (&own)[4], int c, int h) {
+// X[s][o] = sum_d T[rb + s][d] * Own[o][d], s = 0..31
+__device__ __forceinline__ f32x16 first_product(const char* img, int rb, const bf16x8 (&own)[4], int c, int h) {
   f32x16 x;
 #pragma unroll
   for (int e = 0; e < 16; ++e) x[e] = 0.f;
+  const int row = rb + c;
+  const int sw = swz(row);
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Tn + c * TN_STRIDE + kk * 32 + h * 16);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * kk + h) ^ sw) << 4));
     x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, own[kk], x, 0, 0, 0);
   }
   return x;
 }
 
-// Yt[blk][d][o] += sum_s Tt[32*blk + d][s] * X[s][o]   (X given as fp32 accumulator)
-__device__ __forceinline__ void second_product(const char* Tt, const f32x16& x, f32x16 (&y)[2], int c, int h) {
+// Yt[blk][d][o] += sum_s T[rb + s][32 blk + d] * X[s][o]   (X = fp32 accumulator, s = 0..31)
+__device__ __forceinline__ void second_product(const char* img, int rb, const f32x16& x, f32x16 (&y)[2], int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int h = g >> 1, q = i >> 2, p = i & 3;
 #pragma unroll
   for (int sI = 0; sI < 2; ++sI) {
     bf16x8 b;
@@ -85,10 +97,15 @@ __device__ __forceinline__ void second_product(const char* Tt, const f32x16& x, 
     for (int j = 0; j < 8; ++j) b[j] = (bf16_t)x[8 * sI + j];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const char* p = Tt + (32 * blk + c) * TT_STRIDE + (16 * sI + 4 * h) * 2;
-      const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
-      const bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 16);
-      const bf16x8 a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      bf16x4 part[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = rb + 16 * sI + 8 * half + 4 * h + q;
+        const int col = 32 * blk + 16 * (g & 1) + 4 * p;
+        const char* addr = img + row * 128 + ((((col >> 3) ^ swz(row))) << 4) + (col & 7) * 2;
+        part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)addr);
+      }
+      const bf16x8 a = __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
       y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[blk], 0, 0, 0);
     }
   }
@@ -115,13 +132,15 @@ struct AttnP {
   float dq_scale;
 };
 
+#define ZERO2(y)                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) y[i_][e_] = 0.f
+
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Kn = smem;
-  char* Vt = smem + TN_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
@@ -133,47 +152,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
 
   bf16x8 qf[4];
   load_owner(qf, qb, d.q_st, q, Tq, h);
-
   f32x16 o[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
+  ZERO2(o);
   float m = -INFINITY, l = 0.f;
 
-  const int ntiles = (Tk + 31) / 32;
-  u32x4 kreg, vreg;
-  tile_fetch(kreg, kb, d.k_st, 0, Tk);
-  tile_fetch(vreg, vb, d.v_st, 0, Tk);
-  tile_commit_nat(Kn, kreg);
-  tile_commit_tr(Vt, vreg);
+  const int ntiles = (Tk + TROWS - 1) / TROWS;
+  stage_img(smem, kb, d.k_st, 0, Tk, wave, lane);
+  stage_img(smem + IMG, vb, d.v_st, 0, Tk, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int cur = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) {
-      tile_fetch(kreg, kb, d.k_st, (tile + 1) * 32, Tk);
-      tile_fetch(vreg, vb, d.v_st, (tile + 1) * 32, Tk);
+    const char* Kimg = smem + cur * 2 * IMG;
+    const char* Vimg = Kimg + IMG;
+    if (tile + 1 < ntiles) {
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_img(nx, kb, d.k_st, (tile + 1) * TROWS, Tk, wave, lane);
+      stage_img(nx + IMG, vb, d.v_st, (tile + 1) * TROWS, Tk, wave, lane);
     }
-    f32x16 s = first_product(Kn, qf, c, h);  // s[key][q]
+    f32x16 s[2];
+    s[0] = first_product(Kimg, 0, qf, c, h);   // s[key][q], keys 0..31 of the tile
+    s[1] = first_product(Kimg, 32, qf, c, h);  // keys 32..63
+    const int key0 = tile * TROWS;
+    const bool edge = (d.mask_mode == 1) || (key0 + TROWS > Tk);  // wave-uniform
     float mx = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = tile * 32 + acc_row(e, h);
-      float x = s[e];
-      if (d.mask_mode == 1 && key <= q) x = x + (-1e9f);
-      if (key >= Tk) x = -INFINITY;
-      s[e] = x;
-      mx = fmaxf(mx, x);
+    for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float x = s[rbk][e];
+        if (edge) {
+          const int key = key0 + 32 * rbk + acc_row(e, h);
+          if (d.mask_mode == 1 && key <= q) x = x + (-1e9f);
+          if (key >= Tk) x = -INFINITY;
+          s[rbk][e] = x;
+        }
+        mx = fmaxf(mx, x);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mnew = fmaxf(m, mx);
     const float alpha = __expf(m - mnew);
     float rs = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float p = __expf(s[e] - mnew);
-      s[e] = p;
-      rs += p;
+    for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float p = __expf(s[rbk][e] - mnew);
+        s[rbk][e] = p;
+        rs += p;
+      }
     }
     l = l * alpha + rs;
     m = mnew;
@@ -181,13 +209,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-    second_product(Vt, s, o, c, h);
+    second_product(Vimg, 0, s[0], o, lane);
+    second_product(Vimg, 32, s[1], o, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (more) {
-      tile_commit_nat(Kn, kreg);
-      tile_commit_tr(Vt, vreg);
-      __syncthreads();
-    }
+    cur ^= 1;
   }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
@@ -202,12 +228,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
 
 // ------------------------------------------------------------------ dQ pass (owner = query)
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Kn = smem;
-  char* Kt = smem + TN_BYTES;
-  char* Vn = smem + TN_BYTES + TT_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
@@ -219,15 +243,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
   const bf16_t* ob = reinterpret_cast<const bf16_t*>(d.o) + b * d.o_sb + head * HD;
   const bf16_t* dob = reinterpret_cast<const bf16_t*>(d.d_o) + b * d.do_sb + head * HD;
 
-  bf16x8 qf[4], dof[4], of[4];
-  load_owner(qf, qb, d.q_st, q, Tq, h);
-  load_owner(dof, dob, d.do_st, q, Tq, h);
-  load_owner(of, ob, d.o_st, q, Tq, h);
+  bf16x8 qf[4], dof[4];
   float delta = 0.f;
+  {
+    bf16x8 of[4];
+    load_owner(qf, qb, d.q_st, q, Tq, h);
+    load_owner(dof, dob, d.do_st, q, Tq, h);
+    load_owner(of, ob, d.o_st, q, Tq, h);
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+      for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+  }
   delta += __shfl_xor(delta, 32, 64);
   float m = 0.f, linv = 0.f;
   if (q < Tq) {
@@ -236,45 +263,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
     linv = d.stats[si * 2 + 1];
     if (h == 0) d.delta[si] = delta;
   }
-
   f32x16 dq[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+  ZERO2(dq);
 
-  const int ntiles = (Tk + 31) / 32;
-  u32x4 kreg, vreg;
-  tile_fetch(kreg, kb, d.k_st, 0, Tk);
-  tile_fetch(vreg, vb, d.v_st, 0, Tk);
-  tile_commit_nat(Kn, kreg);
-  tile_commit_tr(Kt, kreg);
-  tile_commit_nat(Vn, vreg);
+  const int ntiles = (Tk + TROWS - 1) / TROWS;
+  stage_img(smem, kb, d.k_st, 0, Tk, wave, lane);
+  stage_img(smem + IMG, vb, d.v_st, 0, Tk, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int cur = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
-    const bool more = tile + 1 < ntiles;
-    if (more) {
-      tile_fetch(kreg, kb, d.k_st, (tile + 1) * 32, Tk);
-      tile_fetch(vreg, vb, d.v_st, (tile + 1) * 32, Tk);
+    const char* Kimg = smem + cur * 2 * IMG;
+    const char* Vimg = Kimg + IMG;
+    if (tile + 1 < ntiles) {
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_img(nx, kb, d.k_st, (tile + 1) * TROWS, Tk, wave, lane);
+      stage_img(nx + IMG, vb, d.v_st, (tile + 1) * TROWS, Tk, wave, lane);
     }
-    f32x16 s = first_product(Kn, qf, c, h);    // s[key][q]
-    f32x16 dp = first_product(Vn, dof, c, h);  // dp[key][q]
+    const int key0 = tile * TROWS;
+    const bool edge = (d.mask_mode == 1) || (key0 + TROWS > Tk);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int key = tile * 32 + acc_row(e, h);
-      float x = s[e];
-      if (d.mask_mode == 1 && key <= q) x = x + (-1e9f);
-      const float p = (key < Tk) ? __expf(x - m) * linv : 0.f;
-      s[e] = p * (dp[e] - delta);  // dS
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      f32x16 s = first_product(Kimg, 32 * rbk, qf, c, h);    // s[key][q]
+      f32x16 dp = first_product(Vimg, 32 * rbk, dof, c, h);  // dp[key][q]
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float x = s[e];
+        float p;
+        if (edge) {
+          const int key = key0 + 32 * rbk + acc_row(e, h);
+          if (d.mask_mode == 1 && key <= q) x = x + (-1e9f);
+          p = (key < Tk) ? __expf(x - m) * linv : 0.f;
+        } else {
+          p = __expf(x - m) * linv;
+        }
+        s[e] = p * (dp[e] - delta);  // dS
+      }
+      second_product(Kimg, 32 * rbk, s, dq, lane);  // dQt[d][q] += sum_key K[key][d] dS[key][q]
     }
-    second_product(Kt, s, dq, c, h);  // dQt[d][q] += sum_key K[key][d] dS[key][q]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (more) {
-      tile_commit_nat(Kn, kreg);
-      tile_commit_tr(Kt, kreg);
-      tile_commit_nat(Vn, vreg);
-      __syncthreads();
-    }
+    cur ^= 1;
   }
   bf16_t* dqb = reinterpret_cast<bf16_t*>(d.dq) + b * d.dq_sb + head * HD;
   store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale);
@@ -282,14 +311,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
 
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qn = smem;
-  char* Qt = Qn + TN_BYTES;
-  char* On = Qt + TT_BYTES;
-  char* Ot = On + TN_BYTES;
-  float* rowc = reinterpret_cast<float*>(Ot + TT_BYTES);  // [3][32]: m, linv, delta of the q tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][3][64] floats
   const tmi_attn_desc& d = P.d;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
@@ -301,70 +326,77 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP P) {
   const bf16_t* dob = reinterpret_cast<const bf16_t*>(d.d_o) + b * d.do_sb + head * HD;
   const float* stats = d.stats + (b * d.H + head) * Tq * 2;
   const float* deltas = d.delta + (b * d.H + head) * Tq;
+  float* rowc_base = reinterpret_cast<float*>(smem + 4 * IMG);
 
   bf16x8 kf[4], vf[4];
   load_owner(kf, kb, d.k_st, key, Tk, h);
   load_owner(vf, vb, d.v_st, key, Tk, h);
-
   f32x16 dk[2], dv[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dk[i][e] = dv[i][e] = 0.f;
+  ZERO2(dk);
+  ZERO2(dv);
 
-  const int ntiles = (Tq + 31) / 32;
-  u32x4 qreg, oreg;
-  float creg = 0.f;
-  auto fetch_consts = [&](int row0) {
-    // threads 0..95: (which = t/32, r = t%32)
+  // per-tile row constants: threads 0..191 carry (which = t / 64, r = t % 64)
+  auto load_consts = [&](int row0) -> float {
     const int t = threadIdx.x;
-    if (t < 96) {
-      const int which = t >> 5, r = t & 31, qi = row0 + r;
-      float v = 0.f;
+    float v = 0.f;
+    if (t < 192) {
+      const int which = t >> 6, qi = row0 + (t & 63);
       if (qi < Tq) v = which == 0 ? stats[qi * 2] : (which == 1 ? stats[qi * 2 + 1] : deltas[qi]);
-      creg = v;
     }
+    return v;
   };
-  tile_fetch(qreg, qb, d.q_st, 0, Tq);
-  tile_fetch(oreg, dob, d.do_st, 0, Tq);
-  fetch_consts(0);
-  tile_commit_nat(Qn, qreg);
-  tile_commit_tr(Qt, qreg);
-  tile_commit_nat(On, oreg);
-  tile_commit_tr(Ot, oreg);
-  if (threadIdx.x < 96) rowc[threadIdx.x] = creg;
+
+  const int ntiles = (Tq + TROWS - 1) / TROWS;
+  stage_img(smem, qb, d.q_st, 0, Tq, wave, lane);
+  stage_img(smem + IMG, dob, d.do_st, 0, Tq, wave, lane);
+  {
+    const float cv = load_consts(0);
+    if (threadIdx.x < 192) rowc_base[threadIdx.x] = cv;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int cur = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
+    const char* Qimg = smem + cur * 2 * IMG;
+    const char* Oimg = Qimg + IMG;
+    const float* rowc = rowc_base + cur * 192;
+    float cnext = 0.f;
     const bool more = tile + 1 < ntiles;
     if (more) {
-      tile_fetch(qreg, qb, d.q_st, (tile + 1) * 32, Tq);
-      tile_fetch(oreg, dob, d.do_st, (tile + 1) * 32, Tq);
-      fetch_consts((tile + 1) * 32);
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_img(nx, qb, d.q_st, (tile + 1) * TROWS, Tq, wave, lane);
+      stage_img(nx + IMG, dob, d.do_st, (tile + 1) * TROWS, Tq, wave, lane);
+      cnext = load_consts((tile + 1) * TROWS);
     }
-    f32x16 s = first_product(Qn, kf, c, h);   // s[q][key]
-    f32x16 dp = first_product(On, vf, c, h);  // dp[q][key]
-    f32x16 ds;
+    const int q0 = tile * TROWS;
+    const bool edge = (d.mask_mode == 1) || (q0 + TROWS > Tq);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = acc_row(e, h);
-      const int qi = tile * 32 + r;
-      float x = s[e];
-      if (d.mask_mode == 1 && key <= qi) x = x + (-1e9f);
-      const float p = (qi < Tq) ? __expf(x - rowc[r]) * rowc[32 + r] : 0.f;
-      s[e] = p;
-      ds[e] = p * (dp[e] - rowc[64 + r]);
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      f32x16 s = first_product(Qimg, 32 * rbk, kf, c, h);   // s[q][key]
+      f32x16 dp = first_product(Oimg, 32 * rbk, vf, c, h);  // dp[q][key]
+      f32x16 ds;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * rbk + acc_row(e, h);
+        float x = s[e];
+        float p;
+        if (edge) {
+          const int qi = q0 + r;
+          if (d.mask_mode == 1 && key <= qi) x = x + (-1e9f);
+          p = (qi < Tq) ? __expf(x - rowc[r]) * rowc[64 + r] : 0.f;
+        } else {
+          p = __expf(x - rowc[r]) * rowc[64 + r];
+        }
+        s[e] = p;
+        ds[e] = p * (dp[e] - rowc[128 + r]);
+      }
+      second_product(Oimg, 32 * rbk, s, dv, lane);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
+      second_product(Qimg, 32 * rbk, ds, dk, lane);  // dKt[d][key] += sum_q Q[q][d] dS[q][key]
     }
-    second_product(Ot, s, dv, c, h);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
-    second_product(Qt, ds, dk, c, h);  // dKt[d][key] += sum_q Q[q][d] dS[q][key]
+    if (more && threadIdx.x < 192) rowc_base[(cur ^ 1) * 192 + threadIdx.x] = cnext;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (more) {
-      tile_commit_nat(Qn, qreg);
-      tile_commit_tr(Qt, qreg);
-      tile_commit_nat(On, oreg);
-      tile_commit_tr(Ot, oreg);
-      if (threadIdx.x < 96) rowc[threadIdx.x] = creg;
-      __syncthreads();
-    }
+    cur ^= 1;
   }
   bf16_t* dkb = reinterpret_cast<bf16_t*>(d.dk) + b * d.dk_sb + head * HD;
   bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
@@ -394,7 +426,7 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   P.d = *dp;
   P.dq_scale = 1.f;
   dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), TN_BYTES + TT_BYTES, reinterpret_cast<hipStream_t>(stream), P);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
   return tmi_check_launch("tmi_attn_fwd");
 }
 
@@ -409,10 +441,10 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.dq_scale = dp->dq_scale;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 gq((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 2 * TN_BYTES + TT_BYTES, s, P);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 4 * IMG, s, P);
   int rc = tmi_check_launch("tmi_attn_bwd(dq)");
   if (rc) return rc;
   dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 2 * TN_BYTES + 2 * TT_BYTES + 96 * sizeof(float), s, P);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 4 * IMG + 2 * 192 * sizeof(float), s, P);
   return tmi_check_launch("tmi_attn_bwd(dkv)");
 }

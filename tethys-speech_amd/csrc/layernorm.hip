@@ -89,12 +89,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// Each wave walks rows blockIdx*4+wave, +gridDim*4, ...; dgamma/dbeta partials are folded over
+// the block's 4 waves in LDS and added to the fp32 gradient (zeroed by the caller) with one
+// atomic per column per block: 256 contiguous bytes per wave-instruction.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     T* __restrict__ dx, float* __restrict__ part, int64_t rows,
-                                                     int C, int accumulate_dx, int nparts) {
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows, int C,
+                                                     int accumulate_dx) {
   using IO = RowIO<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][C]
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
   for (int i = 0; i < LN_E; ++i) dg[i] = db[i] = 0.f;
   const float invC = 1.0f / (float)C;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nparts * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     float xv[LN_E], dv[LN_E];
     IO::load(x + row * C, C, lane, xv);
     IO::load(dy + row * C, C, lane, dv);
@@ -137,7 +141,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     IO::store(dx + row * C, C, lane, dv);
   }
-  // fold the 4 waves' column partials and write this block's partial rows
 #pragma unroll
   for (int j = 0; j < IO::NCH; ++j) {
     const int c0 = (j * 64 + lane) * IO::VEC;
@@ -157,31 +160,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       a += red[(w * 2 + 0) * C + c];
       b += red[(w * 2 + 1) * C + c];
     }
-    part[(int64_t)blockIdx.x * C + c] = a;
-    part[((int64_t)nparts + blockIdx.x) * C + c] = b;
-  }
-}
-
-// 64 columns per block, 4 partial-row lanes per column, folded through LDS in a fixed order
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                          int64_t P, int64_t N, int accumulate) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int64_t n = (int64_t)blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (n < N)
-    for (int64_t p = pg; p < P; p += 4) s += part[p * N + n];
-  red[pg][c] = s;
-  __syncthreads();
-  if (pg == 0 && n < N) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    out[n] = accumulate ? out[n] + t : t;
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ part,
-                                                     int64_t rows, int64_t N, int nparts) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
+                                                     int64_t rows, int64_t N) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[4][64 * VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -190,7 +176,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, i
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   if (c0 < N) {
-    for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)nparts * 4) {
+    for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)gridDim.y * 4) {
       const u32x4 raw = *reinterpret_cast<const u32x4*>(dy + row * ld + c0);
       const T* e = reinterpret_cast<const T*>(&raw);
 #pragma unroll
@@ -202,7 +188,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, i
   __syncthreads();
   for (int c = threadIdx.x; c < 64 * VEC; c += 256) {
     const int64_t n = (int64_t)blockIdx.x * 64 * VEC + c;
-    if (n < N) part[(int64_t)blockIdx.y * N + n] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    if (n < N) atomicAdd(out + n, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
   }
 }
 
@@ -247,68 +233,48 @@ extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float*
   return tmi_check_launch("tmi_layernorm_fwd");
 }
 
-extern "C" int64_t tmi_layernorm_bwd_parts(int64_t rows) {
-  int64_t p = rows / 32;
-  if (p < 1) p = 1;
-  if (p > 512) p = 512;
-  return p;
-}
-
 extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                 const float* rstd, void* dx, float* part, int64_t rows, int64_t C,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                                  int32_t accumulate_dx, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !part || rows <= 0 || C <= 0 || C > 64 * LN_E || C % vec ||
-      !al16(x) || !al16(dy) || !al16(dx)) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > 64 * LN_E ||
+      C % vec || !al16(x) || !al16(dy) || !al16(dx)) {
     tmi_set_error("tmi_layernorm_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nparts = (int)tmi_layernorm_bwd_parts(rows);
+  int64_t blocks = (rows + 7) / 8;  // two rows per wave: enough waves in flight to cover HBM latency
+  if (blocks > 2048) blocks = 2048;
   const size_t lds = (size_t)8 * C * sizeof(float);
   if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nparts), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x,
-                       gamma, mean, rstd, (bf16_t*)dx, part, rows, (int)C, accumulate_dx, nparts);
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)dy,
+                       (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx);
   else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nparts), dim3(256), lds, s, (const float*)dy, (const float*)x,
-                       gamma, mean, rstd, (float*)dx, part, rows, (int)C, accumulate_dx, nparts);
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)dy,
+                       (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx);
   else
     return TMI_ERR_UNSUPPORTED;
   return tmi_check_launch("tmi_layernorm_bwd");
 }
 
-extern "C" int tmi_reduce_rows(const float* part, float* out, int64_t P, int64_t N, int32_t accumulate,
-                               void* stream) {
-  if (!part || !out || P <= 0 || N <= 0) {
-    tmi_set_error("tmi_reduce_rows: bad argument");
-    return TMI_ERR_INVALID;
-  }
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), part, out, P, N, accumulate);
-  return tmi_check_launch("tmi_reduce_rows");
-}
-
-extern "C" int64_t tmi_colsum_parts(int64_t rows) {
-  int64_t p = rows / 64;
-  if (p < 1) p = 1;
-  if (p > 256) p = 256;
-  return p;
-}
-
-extern "C" int tmi_colsum(const void* dy, int64_t ld, float* part, int64_t rows, int64_t N, int32_t dtype,
+extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
                           void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!dy || !part || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy)) {
+  if (!dy || !out || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy)) {
     tmi_set_error("tmi_colsum: bad argument (N and ld must be multiples of 16 bytes)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int nparts = (int)tmi_colsum_parts(rows);
-  dim3 grid((unsigned)((N + 64 * vec - 1) / (64 * vec)), (unsigned)nparts);
+  const int64_t xb = (N + 64 * vec - 1) / (64 * vec);
+  int64_t yb = (rows + 31) / 32;  // 8 rows per wave
+  const int64_t cap = (1024 + xb - 1) / xb;
+  if (yb > cap) yb = cap;
+  if (yb < 1) yb = 1;
+  dim3 grid((unsigned)xb, (unsigned)yb);
   if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ld, part, rows, N, nparts);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ld, out, rows, N);
   else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ld, part, rows, N, nparts);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ld, out, rows, N);
   else
     return TMI_ERR_UNSUPPORTED;
   return tmi_check_launch("tmi_colsum");

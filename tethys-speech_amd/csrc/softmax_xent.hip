@@ -160,28 +160,47 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restric
 }
 
 // Block r owns token id(r) iff no earlier row has the same id; it then sums dy over every
-// row with that id, in row order.
+// row with that id, in row order (deterministic).  The matching rows are compacted into an
+// LDS list first so the column sums run 8 independent loads deep (the pad token owns ~40 %
+// of all positions: a serial chain over them was the whole kernel's duration).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ labels, const T* __restrict__ dy,
                                                         float* __restrict__ dtable, int n, int S, int D, int start_id) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned char* match = reinterpret_cast<unsigned char*>(smem);
-  __shared__ int dup;
+  int* list = reinterpret_cast<int*>(smem);  // [n]
+  __shared__ int dup, cnt;
   const int r = blockIdx.x;
   const int id = dec_id(labels, r, S, start_id);
-  if (threadIdx.x == 0) dup = 0;
+  if (threadIdx.x == 0) { dup = 0; cnt = 0; }
   __syncthreads();
-  for (int q = threadIdx.x; q < n; q += 256) {
-    const bool same = dec_id(labels, q, S, start_id) == id;
-    match[q] = same ? 1 : 0;
-    if (same && q < r) dup = 1;
-  }
+  for (int q = threadIdx.x; q < r; q += 256)
+    if (dec_id(labels, q, S, start_id) == id) dup = 1;
   __syncthreads();
   if (dup) return;
+  if (threadIdx.x < 64) {  // one wave builds the ordered list with ballot prefix sums
+    int base = 0;
+    for (int q0 = r; q0 < n; q0 += 64) {
+      const int q = q0 + threadIdx.x;
+      const bool hit = q < n && dec_id(labels, q, S, start_id) == id;
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = q;
+      base += __popcll(m);
+    }
+    if (threadIdx.x == 0) cnt = base;
+  }
+  __syncthreads();
+  const int k = cnt;
   for (int c = threadIdx.x; c < D; c += 256) {
     float s = 0.f;
-    for (int q = r; q < n; ++q)
-      if (match[q]) s += to_f32(dy[(int64_t)q * D + c]);
+    int i = 0;
+    for (; i + 8 <= k; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = to_f32(dy[(int64_t)list[i + u] * D + c]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < k; ++i) s += to_f32(dy[(int64_t)list[i] * D + c]);
     dtable[(int64_t)id * D + c] = s;
   }
 }
@@ -261,13 +280,13 @@ extern "C" int tmi_embed_fwd(const int32_t* labels, const float* table, const fl
 
 extern "C" int tmi_embed_bwd(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
                              int64_t D, int32_t start_id, int32_t dtype, void* stream) {
-  if (!labels || !dy || !dtable || B <= 0 || S <= 0 || D <= 0 || B * S > 65536) {
-    tmi_set_error("tmi_embed_bwd: bad argument (B*S <= 65536)");
+  if (!labels || !dy || !dtable || B <= 0 || S <= 0 || D <= 0 || B * S > 16384) {
+    tmi_set_error("tmi_embed_bwd: bad argument (B*S <= 16384)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int n = (int)(B * S);
-  const size_t lds = (size_t)((n + 15) / 16) * 16;
+  const size_t lds = (size_t)n * sizeof(int);
   if (dtype == TMI_BF16)
     hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(n), dim3(256), lds, s, labels, (const bf16_t*)dy, dtable, n,
                        (int)S, (int)D, start_id);

@@ -102,33 +102,19 @@ def layernorm_fwd(x2d, gamma, beta, y2d, mean, rstd, eps):
           "tmi_layernorm_fwd")
 
 
-def layernorm_bwd_parts(rows: int) -> int:
-    return int(lib().tmi_layernorm_bwd_parts(rows))
-
-
-def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, part, dgamma, dbeta, accumulate_dx=False):
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, accumulate_dx=False):
+    """dgamma / dbeta are accumulated (atomics): zero them first (the grad arena is)."""
     rows, Cn = x2d.shape
-    P = layernorm_bwd_parts(rows)
     check(lib().tmi_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                  rstd.data_ptr(), dx2d.data_ptr(), part.data_ptr(), rows, Cn,
+                                  rstd.data_ptr(), dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
                                   1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
-    s = stream()
-    check(lib().tmi_reduce_rows(part.data_ptr(), dgamma.data_ptr(), P, Cn, 0, s), "tmi_reduce_rows")
-    check(lib().tmi_reduce_rows(part.data_ptr() + P * Cn * 4, dbeta.data_ptr(), P, Cn, 0, s), "tmi_reduce_rows")
 
 
-def colsum_parts(rows: int) -> int:
-    return int(lib().tmi_colsum_parts(rows))
-
-
-def bias_grad(dy2d, part, dbias, accumulate=False):
-    """dbias[N] (+)= sum over rows of dy2d[rows, N]."""
+def bias_grad(dy2d, dbias):
+    """dbias[N] += sum over rows of dy2d[rows, N] (atomics: zero dbias first)."""
     rows, N = dy2d.shape
-    P = colsum_parts(rows)
-    check(lib().tmi_colsum(dy2d.data_ptr(), dy2d.stride(0), part.data_ptr(), rows, N, dt(dy2d), stream()),
+    check(lib().tmi_colsum(dy2d.data_ptr(), dy2d.stride(0), dbias.data_ptr(), rows, N, dt(dy2d), stream()),
           "tmi_colsum")
-    check(lib().tmi_reduce_rows(part.data_ptr(), dbias.data_ptr(), P, N, 1 if accumulate else 0, stream()),
-          "tmi_reduce_rows")
 
 
 def gelu_bwd(dy, u, dx):

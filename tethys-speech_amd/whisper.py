@@ -365,8 +365,6 @@ class WhisperForConditionalGeneration:
         self._buf("dqkv", (Rm, 3 * d))
         self._buf("dkvc", (R, 2 * d))
         self._buf("dU", (Rm, ff))
-        nparts = max(ops.layernorm_bwd_parts(Rm), ops.colsum_parts(Rm), ops.colsum_parts(B * (self.Tp1 + slack)))
-        self._buf("part", (2 * nparts * max(3 * d, ff),), f32)
         He, Hd = cfg.encoder_attention_heads, cfg.decoder_attention_heads
         if self.precision == "bf16":
             for i in range(cfg.encoder_layers):
@@ -407,7 +405,7 @@ class WhisperForConditionalGeneration:
                  splitk=self._splitk(K_in, N, M))
         bname = wname.replace(".kernel", ".bias")
         if bname in self.arena.offsets:
-            ops.bias_grad(dy2d, self.ws["part"], self.arena.grad(bname))
+            ops.bias_grad(dy2d, self.arena.grad(bname))
         if dx2d is not None:
             ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
                      accumulate=accumulate_dx, aux_in=aux_in)
@@ -429,8 +427,7 @@ class WhisperForConditionalGeneration:
     def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate):
         a = self.arena
         ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
-                          dx2d, self.ws["part"], a.grad(pname + ".gamma"), a.grad(pname + ".beta"),
-                          accumulate_dx=accumulate)
+                          dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
 
     # attention: q/k/v given as (tensor2d, column offset); rows are (b, t) with Tq / Tk per batch
     def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask):
@@ -633,10 +630,9 @@ class WhisperForConditionalGeneration:
         du2 = du2pad[:, 1:]  # row 0 of every batch stays zero (the "t-1" term of the first output)
         for b in range(B):  # gelu_bwd needs contiguous spans: one per batch
             ops.gelu_bwd(dres[b * T:(b + 1) * T], ws["u2"][b], du2[b])
-        part = ws["part"]
         gb2 = a.grad("encoder.conv2.bias")
         for b in range(B):
-            ops.bias_grad(du2[b], part, gb2, accumulate=b > 0)
+            ops.bias_grad(du2[b], gb2)
         gw2 = a.grad("encoder.conv2.kernel").view(3 * d, d)
         ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
                  b_skb=du2pad.stride(0), b_off=d, splitk=self._splitk(3 * d, d, T, B))
@@ -652,7 +648,7 @@ class WhisperForConditionalGeneration:
         dh1pad[:, self.pl2 + self.T1:].zero_()
         gb1 = a.grad("encoder.conv1.bias")
         for b in range(B):
-            ops.bias_grad(dh1pad[b, self.pl2:self.pl2 + self.T1], part, gb1, accumulate=b > 0)
+            ops.bias_grad(dh1pad[b, self.pl2:self.pl2 + self.T1], gb1)
         gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
                  b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=self._splitk(3 * Cn, d, self.T1, B))
