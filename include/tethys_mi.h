@@ -57,7 +57,9 @@ const char* tmi_last_error(void);
  *   if aux_in:  v *= gelu_erf'(aux_in[..])   (backward through GELU; layout as C)
  *   if resid:   v += resid[b*r_sb + m*r_ld + n]  (residual add W:228,234 / PE add W:339)
  * splitk > 1 partitions the (kb,k) range over extra workgroups and accumulates with
- * fp32 atomics into a PRE-ZEROED fp32 C (no epilogue terms allowed).
+ * fp32 atomics into a PRE-ZEROED fp32 C (no epilogue terms allowed); splitk == 0 lets the
+ * library choose (it only splits epilogue-free fp32-output GEMMs, i.e. weight gradients, and
+ * then C must be pre-zeroed); splitk == 1 never splits.
  * in_dtype: type of A and B; out_dtype: type of C, aux_*, resid.  Valid pairs:
  * (F32,F32), (BF16,BF16), (BF16,F32).  fp32 inputs use the exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32); bf16 inputs use v_mfma_f32_32x32x16_bf16.

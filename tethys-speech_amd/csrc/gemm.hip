@@ -228,7 +228,7 @@ int launch(const tmi_gemm_desc& d, hipStream_t stream) {
   P.tiles_m = (int)((d.M + BM - 1) / BM);
   P.tiles_n = (int)((d.N + BN - 1) / BN);
   P.ktiles = (int)((d.K + BK - 1) / BK);
-  const int splitk = d.splitk > 1 ? d.splitk : 1;
+  const int splitk = d.splitk > 1 ? d.splitk : 1;  // 0 (auto) means 1 on the generic path
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)d.nbatch);
   hipLaunchKernelGGL((gemm_kernel<T, TC>), grid, dim3(256), 2 * TILE_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm");
@@ -259,6 +259,7 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
     tmi_set_error("tmi_gemm: nbatch/splitk exceed grid limits");
     return TMI_ERR_INVALID;
   }
+  if (d.splitk < 0) d.splitk = 1;
   if (d.splitk > 1) {
     if (d.out_dtype != TMI_F32 || d.bias || d.accumulate || d.act || d.aux_out || d.aux_in ||
         d.resid || d.scale_cols > 0) {

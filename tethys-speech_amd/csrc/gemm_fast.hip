@@ -6,11 +6,14 @@
 //       ds_read_b64_tr_b16 (hardware transpose of a 4(k) x 16(col) block), swizzle
 //       phys_chunk = chunk ^ ((k & 3) << 2)
 // forward X·W = (KC, KS) straight from the natural Keras [in,out] kernel; dgrad dY·Wᵀ = (KC, KC);
-// wgrad Xᵀ·dY = (KS, KS).  128x128 output tile per 256-thread workgroup (waves 2x2, 64x64 each,
-// MFMA 32x32x16 bf16), BK = 64.  Tiles are staged global -> LDS directly
-// (global_load_lds_dwordx4), double-buffered: the next tile's DMA is in flight under the
-// current tile's MFMAs, one barrier per K-tile.  The LDS image is lane-linear as the DMA
-// requires; the swizzle is applied to the per-lane SOURCE address and again on the read.
+// wgrad Xᵀ·dY = (KS, KS).  Two tile configurations (MFMA 32x32x16 bf16, BK = 64): 256x256 per
+// 512-thread workgroup, 8 waves as 2x4, each wave 128x64 (128 accumulator registers) — twice
+// the MFMA work per staged byte and per LDS-DMA instruction issued — and 128x128 per 256-thread
+// workgroup (waves 2x2 of 64x64, two workgroups per CU) for narrow / small problems.  Tiles are
+// staged global -> LDS directly (global_load_lds_dwordx4), double-buffered: the next K-tile's
+// DMA is in flight under the current tile's MFMAs, one barrier per K-tile.
+// The LDS image is lane-linear as the DMA requires; the swizzle is applied to the per-lane
+// SOURCE address and again on the read.
 // Epilogue: accumulators go through LDS (fp32, per-wave 64x64) and leave as whole 16-byte
 // row segments — bias/scale/accumulate/GELU/GELU'/residual are applied on 8-column chunks
 // with 16-byte loads and stores (a 2-byte-per-lane store tail is store-issue-bound).
@@ -44,6 +47,8 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 struct FastParams {
   tmi_gemm_desc d;
   int tiles_m, tiles_n, ktiles;
+  int xm, xn;        // XCD partition of the tile grid: xm * xn == 8
+  int ptm, ptn;      // tiles per XCD partition along m / n
   int wide;          // epilogue may use 16-byte accesses on C / aux / resid
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
@@ -56,12 +61,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// ---- KC staging: 128 rows x 64 k (128 B per row)
+// ---- KC staging: ROWS rows x 64 k (128 B per row); wave-instruction j covers rows 8j..8j+7
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_kc(char* lds, const bf16_t* base, int64_t s_row, int64_t row0, int64_t nrows,
                                          int64_t k0, int wave, int lane) {
+  constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * wave + i;
+  for (int i = 0; i < PER; ++i) {
+    const int j = PER * wave + i;
     const int r = 8 * j + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int64_t grow = row0 + r;
@@ -70,17 +77,21 @@ __device__ __forceinline__ void stage_kc(char* lds, const bf16_t* base, int64_t 
   }
 }
 
-// ---- KS staging: 64 k-rows x 128 cols (256 B per row)
+// ---- KS staging: COLS/128 sub-images of [64 k-rows][128 cols] (256 B per row, 16 KiB each);
+// wave-instruction j covers k-rows 4(j%16)..+3 of sub-image j/16
+template <int COLS, int NW>
 __device__ __forceinline__ void stage_ks(char* lds, const bf16_t* base, int64_t s_k, int64_t col0, int64_t ncols_rd,
                                          int64_t k0, int64_t kend, int wave, int lane) {
+  constexpr int PER = COLS / 8 / NW;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int j = 4 * wave + i;
-    const int kr = 4 * j + (lane >> 4);
+  for (int i = 0; i < PER; ++i) {
+    const int j = PER * wave + i;
+    const int sub = j >> 4, jj = j & 15;
+    const int kr = 4 * jj + (lane >> 4);
     const int c = (lane & 15) ^ ((kr & 3) << 2);
     int64_t gk = k0 + kr;
     gk = gk < kend ? gk : kend - 1;
-    int64_t gc = col0 + c * 8;
+    int64_t gc = col0 + sub * 128 + c * 8;
     gc = gc + 8 <= ncols_rd ? gc : ncols_rd - 8;
     glds16(base + gk * s_k + gc, lds + j * 1024);
   }
@@ -97,7 +108,9 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk
   const int g = lane >> 4, i = lane & 15;
   const int h = g >> 1;
   const int q = i >> 2, p = i & 3;
-  const int col = col_base + 16 * (g & 1) + 4 * p;  // first of this lane's 4 address columns
+  const int colf = col_base + 16 * (g & 1) + 4 * p;  // first of this lane's 4 address columns
+  tile += (colf >> 7) * 16384;                          // 128-column sub-image
+  const int col = colf & 127;
   bf16x4 part[2];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -109,24 +122,27 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk
   return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool A_KS, bool B_KS>
-__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int wr, int wc, int lane,
-                                         f32x16 (&acc)[2][2]) {
+template <bool A_KS, bool B_KS, int MI, int NI>
+__device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int row_base, int col_base, int lane,
+                                         f32x16 (&acc)[MI][NI]) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    bf16x8 a[2], b[2];
+    bf16x8 a[MI], b[NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if constexpr (A_KS) a[i] = frag_ks(As, wr * 64 + i * 32, kk, lane);
-      else a[i] = frag_kc(As, wr * 64 + i * 32 + r, kk, h);
-      if constexpr (B_KS) b[i] = frag_ks(Bs, wc * 64 + i * 32, kk, lane);
-      else b[i] = frag_kc(Bs, wc * 64 + i * 32 + r, kk, h);
+    for (int i = 0; i < MI; ++i) {
+      if constexpr (A_KS) a[i] = frag_ks(As, row_base + i * 32, kk, lane);
+      else a[i] = frag_kc(As, row_base + i * 32 + r, kk, h);
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int i = 0; i < NI; ++i) {
+      if constexpr (B_KS) b[i] = frag_ks(Bs, col_base + i * 32, kk, lane);
+      else b[i] = frag_kc(Bs, col_base + i * 32 + r, kk, h);
+    }
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
   }
 }
@@ -160,31 +176,31 @@ template <> struct Vec8<bf16_t> {
 
 __device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((col * 4) ^ ((row & 1) << 4)); }
 
+// One 64x64 piece of a wave's output (accumulator blocks a00 a01 / a10 a11) whose top-left element
+// is C[mw][nw]; E is the wave's private 16 KiB staging image.
 template <typename TC>
-__device__ __forceinline__ void wide_epilogue(const FastParams& P, f32x16 (&acc)[2][2], char* smem, int64_t m0,
-                                              int64_t n0, int64_t bz, int wave, int lane, bool atomic) {
+__device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16& a00, const f32x16& a01,
+                                              const f32x16& a10, const f32x16& a11, char* E, int64_t mw, int64_t nw,
+                                              int64_t bz, int lane, bool atomic) {
   const tmi_gemm_desc& d = P.d;
-  const int wr = wave >> 1, wc = wave & 1;
-  char* E = smem + wave * 16384;  // this wave's 64x64 fp32 image
   {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int row = mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-          *reinterpret_cast<float*>(E + epi_off(row, ni * 32 + c)) = acc[mi][ni][reg];
-        }
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      *reinterpret_cast<float*>(E + epi_off(row, c)) = a00[reg];
+      *reinterpret_cast<float*>(E + epi_off(row, 32 + c)) = a01[reg];
+      *reinterpret_cast<float*>(E + epi_off(32 + row, c)) = a10[reg];
+      *reinterpret_cast<float*>(E + epi_off(32 + row, 32 + c)) = a11[reg];
+    }
   }
   TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
   if (atomic) {  // split-K: fp32 atomics, 256 contiguous bytes per wave-instruction
     if constexpr (sizeof(TC) == 4) {
-      const int64_t n = n0 + wc * 64 + lane;
+      const int64_t n = nw + lane;
       if (n < d.N) {
         for (int row = 0; row < 64; ++row) {
-          const int64_t m = m0 + wr * 64 + row;
+          const int64_t m = mw + row;
           if (m >= d.M) break;
           atomicAdd(reinterpret_cast<float*>(C) + m * d.ldc + n, *reinterpret_cast<const float*>(E + epi_off(row, lane)));
         }
@@ -196,7 +212,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, f32x16 (&acc)
   const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
   const TC* resid = d.resid ? reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb : nullptr;
   const int chunk = lane & 7;
-  const int64_t n = n0 + wc * 64 + chunk * 8;
+  const int64_t n = nw + chunk * 8;
   if (n >= d.N) return;
   const bool full = P.wide && (n + 8 <= d.N);
   float bv[8];
@@ -205,7 +221,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, f32x16 (&acc)
 #pragma unroll 1
   for (int p = 0; p < 8; ++p) {
     const int row = p * 8 + (lane >> 3);
-    const int64_t m = m0 + wr * 64 + row;
+    const int64_t m = mw + row;
     if (m >= d.M) continue;
     float v[8];
     {
@@ -259,95 +275,141 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, f32x16 (&acc)
   }
 }
 
-template <typename TC, bool A_KS, bool B_KS>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(const FastParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A tile | B tile]
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// CFG 0: 128x128 tile, 4 waves (2x2) of 64x64, 2 stages (64 KiB, two workgroups per CU)
+// CFG 1: 256x256 tile, 8 waves (2x4) of 128x64, 2 stages (128 KiB, one workgroup per CU): twice
+//        the MFMA work per staged byte and per LDS-DMA instruction a wave has to issue
+// SPEC (wave specialisation): the workgroup carries as many LOADER waves as consumer waves; the
+//        loaders only issue the LDS-DMA of the next K-tile, the consumers only read fragments
+//        and issue MFMAs, so no wave serialises ~100-cycle DMA issues with its MFMA stream
+// CFG 2: CFG 0's tile with 4 loader + 4 consumer waves
+// CFG 3: 256x128 tile, 4 consumer waves (2x2) of 128x64 + 4 loader waves (one of each per SIMD)
+template <int CFG> struct Cfg;
+template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <> struct Cfg<1> { static constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <> struct Cfg<2> { static constexpr int BM = 128, BN = 128, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = true; };
+template <> struct Cfg<3> { static constexpr int BM = 256, BN = 128, WM = 128, WN = 64, NSTAGE = 2; static constexpr bool SPEC = true; };
+
+// ABL (diagnostics, compile-time so the production loop is untouched): 2 = no MFMA/fragment reads,
+// 4 = no staging after the prologue
+template <typename TC, bool A_KS, bool B_KS, int CFG, int ABL = 0>
+__global__ __launch_bounds__((Cfg<CFG>::BM / Cfg<CFG>::WM) * (Cfg<CFG>::BN / Cfg<CFG>::WN) * (Cfg<CFG>::SPEC ? 128 : 64))
+void gemm_fast_kernel(const FastParams P) {
+  using K = Cfg<CFG>;
+  constexpr int BM = K::BM, BN = K::BN, NSTAGE = K::NSTAGE;
+  constexpr int WCOLS = BN / K::WN;           // waves along N
+  constexpr int NW = (BM / K::WM) * WCOLS;
+  constexpr int MI = K::WM / 32, NI = K::WN / 32;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const tmi_gemm_desc& d = P.d;
-  const int nwg = P.tiles_m * P.tiles_n;
-  const int tile = xcd_remap(blockIdx.x, nwg);
-  const int tm = tile / P.tiles_n, tn = tile % P.tiles_n;
-  const int64_t m0 = (int64_t)tm * 128, n0 = (int64_t)tn * 128;
+  // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+  // blockIdx.x % 8 labels the XCD.  The tile grid is cut into xm x xn rectangles, one per XCD,
+  // sized so that an XCD's slice of B stays resident in its 4 MiB L2 while A panels stream.
+  const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+  const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
+  const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
+  if (tm >= P.tiles_m || tn >= P.tiles_n) return;  // padding block of a ragged partition (whole workgroup)
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t bz = blockIdx.z;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool loader = K::SPEC && wave_all >= NW;       // wave-uniform role
+  const bool consumer = !K::SPEC || wave_all < NW;
+  const int wave = loader ? wave_all - NW : wave_all;  // index within its role
+  const int wr = wave / WCOLS, wc = wave % WCOLS;
+  constexpr int NTHREADS = NW * (K::SPEC ? 128 : 64);
 
   const int total_it = (int)d.kbatch * P.ktiles;
   const int nsplit = gridDim.y;
   const int per = (total_it + nsplit - 1) / nsplit;
   const int it0 = blockIdx.y * per;
-  const int it1 = min(total_it, it0 + per);
+  const int nt = min(total_it, it0 + per) - it0;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(d.A) + bz * d.a_sb;
   const bf16_t* Bbase = reinterpret_cast<const bf16_t*>(d.B) + bz * d.b_sb;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   auto stage = [&](int it, int buf) {
     const int kb = it / P.ktiles, kt = it - kb * P.ktiles;
-    char* As = smem + buf * 2 * FT_BYTES;
-    char* Bs = As + FT_BYTES;
-    if constexpr (A_KS) stage_ks(As, Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
-    else stage_kc(As, Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane);
-    if constexpr (B_KS) stage_ks(Bs, Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
-    else stage_kc(Bs, Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane);
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_BYTES;
+    if constexpr (A_KS) stage_ks<BM, NW>(As, Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
+    else stage_kc<BM, NW>(As, Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane);
+    if constexpr (B_KS) stage_ks<BN, NW>(Bs, Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
+    else stage_kc<BN, NW>(Bs, Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane);
   };
-  // K tail (K % 64 != 0, host allows it only when an operand is KS): rows k >= K of a KS image
-  // were loaded from a clamped row; zero them so they contribute nothing
+  // K tail (K % 64 != 0, host allows it only in (KS, KS)): rows k >= K of a KS image were loaded
+  // from a clamped row; zero them so they contribute nothing
   auto zero_tail = [&](int it, int buf) {
-    if constexpr (A_KS || B_KS) {
+    if constexpr (A_KS && B_KS) {
       const int kt = it % P.ktiles;
       const int kvalid = (int)min((int64_t)64, d.K - (int64_t)kt * 64);
       if (kvalid < 64) {
-        char* As = smem + buf * 2 * FT_BYTES;
-        for (int idx = threadIdx.x; idx < (64 - kvalid) * 16; idx += 256) {
-          const int off = kvalid * 256 + idx * 16;
-          if constexpr (A_KS) *reinterpret_cast<u32x4*>(As + off) = u32x4{0u, 0u, 0u, 0u};
-          if constexpr (B_KS) *reinterpret_cast<u32x4*>(As + FT_BYTES + off) = u32x4{0u, 0u, 0u, 0u};
+        char* As = smem + buf * STAGE;
+        constexpr int NIMG = (BM + BN) / 128;  // consecutive 16 KiB [64][256 B] images: A sub-images, then B's
+        for (int idx = threadIdx.x; idx < NIMG * (64 - kvalid) * 16; idx += NTHREADS) {
+          const int img = idx / ((64 - kvalid) * 16), rem = idx % ((64 - kvalid) * 16);
+          *reinterpret_cast<u32x4*>(As + img * 16384 + kvalid * 256 + rem * 16) = u32x4{0u, 0u, 0u, 0u};
         }
         __syncthreads();
       }
     }
   };
 
-  if (it0 < it1) {
-    stage(it0, 0);
+  const bool stager = !K::SPEC || loader;
+  if (nt > 0) {
+    if (stager) stage(it0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int cur = 0;
-    for (int it = it0; it < it1; ++it) {
-      if (it + 1 < it1) stage(it + 1, cur ^ 1);
-      zero_tail(it, cur);
-      const char* As = smem + cur * 2 * FT_BYTES;
-      const char* Bs = As + FT_BYTES;
-      mma_tile<A_KS, B_KS>(As, Bs, wr, wc, lane, acc);
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (ABL != 4 && stager && t + 1 < nt) stage(it0 + t + 1, buf ^ 1);   // next tile's DMA flies under this tile's MFMAs
+      zero_tail(it0 + t, buf);
+      if (ABL != 2 && consumer) {
+        const char* As = smem + buf * STAGE;
+        mma_tile<A_KS, B_KS, MI, NI>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      cur ^= 1;
+      buf ^= 1;
     }
   }
+  if (!consumer) return;
   if (P.dbg & 1) {
-    if (acc[0][0][0] + acc[1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;  // keep acc live
+    if (acc[0][0][0] + acc[MI - 1][NI - 1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;  // keep acc live
     return;
   }
-  wide_epilogue<TC>(P, acc, smem, m0, n0, bz, wave, lane, nsplit > 1);
+  static_assert(NI == 2, "epilogue pieces are 64 columns wide");
+  char* E = smem + wave * 16384;
+#pragma unroll
+  for (int p = 0; p < MI / 2; ++p)
+    wide_epilogue<TC>(P, acc[2 * p][0], acc[2 * p][1], acc[2 * p + 1][0], acc[2 * p + 1][1], E,
+                      m0 + wr * K::WM + p * 64, n0 + wc * K::WN, bz, lane, nsplit > 1);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t rup8(int64_t x) { return (x + 7) / 8 * 8; }
 
-template <typename TC, bool A_KS, bool B_KS>
-int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
+template <typename TC, bool A_KS, bool B_KS, int CFG>
+int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
+  using K = Cfg<CFG>;
+  constexpr int NW = (K::BM / K::WM) * (K::BN / K::WN);
+  constexpr int LDS_BYTES = K::NSTAGE * (K::BM + K::BN) * 128;
+  static_assert(LDS_BYTES >= NW * 16384, "epilogue staging must fit the ring");
   FastParams P;
   P.d = d;
-  P.tiles_m = (int)((d.M + 127) / 128);
-  P.tiles_n = (int)((d.N + 127) / 128);
+  P.tiles_m = (int)((d.M + K::BM - 1) / K::BM);
+  P.tiles_n = (int)((d.N + K::BN - 1) / K::BN);
   P.ktiles = (int)((d.K + 63) / 64);
   P.a_cols_rd = rup8(d.M);
   P.b_cols_rd = rup8(d.N);
@@ -356,10 +418,59 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
-  const int splitk = d.splitk > 1 ? d.splitk : 1;
-  dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)d.nbatch);
-  hipLaunchKernelGGL((gemm_fast_kernel<TC, A_KS, B_KS>), grid, dim3(256), 4 * FT_BYTES, stream, P);
+  auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
+  if constexpr (sizeof(TC) == 2 && !A_KS && CFG < 2) {  // ablation builds exist for the bf16-out KC-A kernels only
+    if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
+    if ((dbg & 6) == 4) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 4>;
+    if (dbg & 6) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  }
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<TC, A_KS, B_KS, CFG>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) {
+    tmi_set_error("tmi_gemm(fast): cannot raise the dynamic LDS limit");
+    return TMI_ERR_LAUNCH;
+  }
+  int splitk = d.splitk > 1 ? d.splitk : 1;
+  if (d.splitk == 0 && d.out_dtype == TMI_F32 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in &&
+      !d.resid && d.scale_cols <= 0) {
+    // auto split-K for weight-gradient shapes: fill the CUs (two workgroups each for the small
+    // tile, one for the large), at least 4 K-tiles per split
+    const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
+    const int64_t its = (int64_t)d.kbatch * P.ktiles;
+    const int64_t slots = (CFG == 1 || CFG == 3) ? 256 : 512;
+    int64_t want = (slots + tiles - 1) / tiles;
+    if (want > its / 4) want = its / 4;
+    if (want > 64) want = 64;
+    splitk = want < 1 ? 1 : (int)want;
+  }
+  // choose the N split so one XCD's share of B (K x N/xn bf16) is <= ~2 MiB
+  static const int force_xn = [] { const char* e = getenv("TMI_GEMM_XN"); return e ? atoi(e) : 0; }();
+  int xn = 1;
+  while (xn < 8 && (double)d.K * (double)d.kbatch * ((double)d.N / xn) * 2.0 > 2.0 * 1048576.0 && P.tiles_n >= 2 * xn) xn *= 2;
+  if (force_xn) xn = force_xn;
+  P.xn = xn;
+  P.xm = 8 / xn;
+  P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
+  P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm(fast)");
+}
+
+template <typename TC, bool A_KS, bool B_KS>
+int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
+  static const int force = [] { const char* e = getenv("TMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
+  // Measured on MI355X (tools/gemm_bench.py): the 256x256 tile wins for bf16-output GEMMs with a
+  // long reduction (K >= 1536: its unoverlapped epilogue is amortised) or whose tile count fills
+  // whole rounds of the 256 CUs; weight gradients (split-K, atomic epilogue) and small problems
+  // run better on the 128x128 tile with two workgroups per CU.
+  const int64_t big_tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nbatch;
+  const double round_eff = (double)big_tiles / (double)(((big_tiles + 255) / 256) * 256);
+  bool big = d.out_dtype == TMI_BF16 && d.M >= 2048 && d.N >= 512 && (d.K * d.kbatch >= 1536 || round_eff >= 0.8);
+  if (force == 2) return launch_cfg<TC, A_KS, B_KS, 2>(d, stream);
+  if (force == 3) return launch_cfg<TC, A_KS, B_KS, 3>(d, stream);
+  if (force >= 0) big = force == 1;
+  return big ? launch_cfg<TC, A_KS, B_KS, 1>(d, stream) : launch_cfg<TC, A_KS, B_KS, 0>(d, stream);
 }
 
 template <bool A_KS, bool B_KS>

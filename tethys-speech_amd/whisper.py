@@ -402,22 +402,13 @@ class WhisperForConditionalGeneration:
         M = x2d.shape[0]
         dW = self.arena.grad(wname).view(K_in, N)
         ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N,
-                 splitk=self._splitk(K_in, N, M))
+                 splitk=0)
         bname = wname.replace(".kernel", ".bias")
         if bname in self.arena.offsets:
             ops.bias_grad(dy2d, self.arena.grad(bname))
         if dx2d is not None:
             ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
                      accumulate=accumulate_dx, aux_in=aux_in)
-
-    def _splitk(self, rows, cols, k_len, kbatch=1):
-        """Split the reduction of a weight-gradient GEMM over extra workgroups when its output
-        has too few 128x128 tiles to fill 256 CUs (fp32 atomics into the zeroed grad arena)."""
-        tiles = -(-rows // 128) * -(-cols // 128)
-        its = kbatch * -(-k_len // (64 if self.precision == "bf16" else 32))
-        if tiles >= 192:
-            return 1
-        return max(1, min(its // 4, -(-512 // tiles)))
 
     def _ln_fwd(self, x2d, pname, y2d, stat):
         a = self.arena
@@ -571,7 +562,7 @@ class WhisperForConditionalGeneration:
         # ================= backward =================
         dres = ws["dres_dec"]
         dW = a.grad("lm_head.kernel")
-        ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp)
+        ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp, splitk=0)
         dtmp = ws["dtmp"][:B * S]
         # dgrad over the padded vocab (pad columns of dlogits are zero): a whole number of K tiles
         ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
@@ -635,7 +626,7 @@ class WhisperForConditionalGeneration:
             ops.bias_grad(du2[b], gb2)
         gw2 = a.grad("encoder.conv2.kernel").view(3 * d, d)
         ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
-                 b_skb=du2pad.stride(0), b_off=d, splitk=self._splitk(3 * d, d, T, B))
+                 b_skb=du2pad.stride(0), b_off=d, splitk=0)
         sd = du2pad.stride(0)
         # even padded rows u = 2j: dY[j]·W0ᵀ + dY[j-1]·W2ᵀ  (kbatch walks the two kernel taps)
         ops.gemm(du2pad, w2, dh1pad, T, d, d, d, 1, 1, ld2, 2 * d, nbatch=B, a_sb=sd, c_sb=dh1pad.stride(0),
@@ -651,7 +642,7 @@ class WhisperForConditionalGeneration:
             ops.bias_grad(dh1pad[b, self.pl2:self.pl2 + self.T1], gb1)
         gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
-                 b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=self._splitk(3 * Cn, d, self.T1, B))
+                 b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=0)
         return ws["loss"]
 
     def __call__(self, features, labels=None, training=True):

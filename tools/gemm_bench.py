@@ -37,7 +37,7 @@ def main():
         bench(f"fwd  (KC,KS) M{M} N{N} K{K}", lambda: ops.gemm(X, W, Y, M, N, K, K, 1, N, 1, N, bias=bias), fl)
         bench(f"fwd+gelu+aux   M{M} N{N} K{K}", lambda: ops.gemm(X, W, Y, M, N, K, K, 1, N, 1, N, bias=bias, act=1, aux_out=dY), fl)
         bench(f"dgrad(KC,KC) M{M} N{K} K{N}", lambda: ops.gemm(dY, W, dX, M, K, N, N, 1, 1, N, K), fl)
-        bench(f"wgrad(KS,KS) M{K} N{N} K{M}", lambda: ops.gemm(X, dY, dW, K, N, M, 1, K, N, 1, N), fl)
+        bench(f"wgrad(KS,KS) M{K} N{N} K{M}", lambda: ops.gemm(X, dY, dW, K, N, M, 1, K, N, 1, N, splitk=0), fl)
     # decoder-sized
     M = 800
     X = torch.randn(M, 768, device=dev).to(bf); W = torch.randn(768, 768, device=dev).to(bf); Y = torch.empty(M, 768, device=dev, dtype=bf)
