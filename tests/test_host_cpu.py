@@ -75,6 +75,10 @@ def test_arena_layout_and_reference_views():
 def test_strategy_buckets_and_env():
     import tethys_speech_amd  # noqa: F401
     from tethys_speech_amd import dist as D
+    s = D.DataParallelStrategy(0, 2, bucket_bytes=4 * 100, init=False)
+    s.begin_gradients(torch.zeros(1000))
+    with pytest.raises(RuntimeError):
+        s.gradients_ready(100, 900)  # not adjacent to the end of the arena
     s = D.DataParallelStrategy(0, 1, bucket_bytes=4 * 100)
     b = s.buckets(250)
     assert b == [(150, 250), (50, 150), (0, 50)]
@@ -138,7 +142,17 @@ def _dp_worker(rank, world, port, q):
         off += n
     loss, g = O.loss_and_grads(p, torch.from_numpy(f[2 * rank:2 * rank + 2]), torch.from_numpy(l[2 * rank:2 * rank + 2]), cfg)
     gflat = torch.cat([g[k].reshape(-1) for k in names])
-    strat.all_reduce_gradients(gflat)  # C1 (bucketed)
+    # C1, overlapped form: ranges become final last-first, buckets fly while "backward" continues
+    strat.begin_gradients(gflat)
+    n = gflat.numel()
+    strat.gradients_ready(2 * n // 3, n)
+    strat.gradients_ready(n // 3, 2 * n // 3)
+    launched = len(strat._works)
+    strat.all_reduce_gradients(gflat)  # sends the remaining head and waits for every bucket
+    assert launched >= 1
+    g2 = torch.cat([g[k].reshape(-1) for k in names])
+    strat.all_reduce_gradients(g2)     # plain bucketed form gives the same sums
+    assert torch.equal(g2, gflat)
     tot = strat.reduce_sum(loss.reshape(1).clone())  # C2
     q.put((rank, gflat.numpy(), float(tot), flat.numpy()))
     dist.destroy_process_group()

@@ -48,7 +48,9 @@ class DataParallelStrategy:
                  bucket_bytes: int = 64 << 20, init: bool = True):
         self.rank, self.world = rank, world
         self.bucket_bytes = bucket_bytes
-        self._pending: List = []
+        self._g = None
+        self._works: List = []
+        self._pend_lo = self._pend_hi = 0
         if world > 1 and init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -71,13 +73,49 @@ class DataParallelStrategy:
             end = start
         return out
 
-    def all_reduce_gradients(self, g: torch.Tensor):
-        """C1: SUM over replicas of the whole gradient arena, bucketed."""
-        if self.world == 1:
+    # -- C1, overlapped with backward ---------------------------------------------------
+    def begin_gradients(self, g: torch.Tensor):
+        """Start a step's gradient exchange.  The model then reports, through
+        ``gradients_ready(lo, hi)``, each arena range whose gradients are final (every kernel
+        that writes it has been enqueued); ranges arrive contiguous and descending, because the
+        arena is in forward order and backward fills it from the end."""
+        self._g = g
+        self._works: List = []
+        self._pend_lo = self._pend_hi = g.numel()
+
+    def gradients_ready(self, lo: int, hi: int):
+        if self.world == 1 or self._g is None:
             return
-        works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in self.buckets(g.numel())]
+        if hi != self._pend_lo:
+            raise RuntimeError(f"gradient ranges must be contiguous and descending: got [{lo},{hi}) after {self._pend_lo}")
+        self._pend_lo = lo
+        if (self._pend_hi - self._pend_lo) * 4 >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        if self._pend_hi > self._pend_lo:
+            # RCCL orders this after everything already enqueued on the compute stream and runs it
+            # on its own stream, under the rest of backward
+            self._works.append(dist.all_reduce(self._g[self._pend_lo:self._pend_hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._pend_hi = self._pend_lo
+
+    def all_reduce_gradients(self, g: torch.Tensor):
+        """C1: SUM over replicas of the whole gradient arena, bucketed.  If ``begin_gradients``
+        opened an overlapped exchange for ``g``, only the not-yet-launched head of the arena is
+        sent now; in every case this returns with the compute stream ordered after all buckets."""
+        if self.world == 1:
+            self._g = None
+            return
+        if getattr(self, "_g", None) is g:
+            self._pend_lo = 0
+            self._launch()
+            works = self._works
+        else:
+            works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in self.buckets(g.numel())]
         for w in works:
             w.wait()
+        self._g = None
+        self._works = []
 
     def reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
         """C2: strategy.reduce(SUM, per_replica_losses, axis=None) (W:848)."""

@@ -17,8 +17,9 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
     Adam); returns ``strategy.reduce(SUM, per_replica_loss)`` as a 1-element device tensor.
     A replica whose slice of a short final batch is empty contributes zero gradients."""
     features, labels = dist_inputs
+    strategy.begin_gradients(model.arena.g)
     if features.shape[0] > 0:
-        loss = model.forward_backward(features, labels)
+        loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready)
     else:
         model.arena.g.zero_()
         loss = torch.zeros(1, dtype=torch.float32, device=model.device)

@@ -475,10 +475,14 @@ class WhisperForConditionalGeneration:
                      c_sb=hd, a_off=po, b_off=b * Tq * qt.stride(0) + qo, c_off=b * Tk * dkt.stride(0) + dko)
 
     # -- forward -------------------------------------------------------------------------
-    def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0):
+    def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
+                         grad_ready=None):
         """One replica's forward + backward (W:826-833).  features [B, n_mels, T_in] fp32,
         labels [B, S] int32, both on the device.  Gradients land in ``arena.g`` (which is
-        zeroed first); returns the device scalar loss (mean over B*(S-1), W:600)."""
+        zeroed first); returns the device scalar loss (mean over B*(S-1), W:600).
+        ``grad_ready(lo, hi)`` is called during backward each time the gradients of the arena
+        range [lo, hi) are final, last range first (the data-parallel strategy all-reduces them
+        under the rest of backward)."""
         cfg = self.config
         B, Cn, T_in = features.shape
         S = labels.shape[1]
@@ -491,6 +495,14 @@ class WhisperForConditionalGeneration:
         T, He, Hd = self.T, cfg.encoder_attention_heads, cfg.decoder_attention_heads
         scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
         a.g.zero_()
+        done = [a.numel]
+
+        def ready(name):
+            """Everything stored at or after parameter ``name`` now has its final gradient."""
+            lo = a.offsets[name]
+            if grad_ready is not None and lo < done[0]:
+                grad_ready(lo, done[0])
+                done[0] = lo
 
         # ---- encoder stem (W:329-339)
         xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
@@ -567,6 +579,7 @@ class WhisperForConditionalGeneration:
         # dgrad over the padded vocab (pad columns of dlogits are zero): a whole number of K tiles
         ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
+        ready("decoder.layer_norm.gamma")
 
         d_enc = ws["d_enc_out"]
         first_cross = True
@@ -595,13 +608,16 @@ class WhisperForConditionalGeneration:
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+            ready(p + ".self_attn_layer_norm.gamma")
         ops.embed_bwd(labels, dres, a.grad("decoder.embed_tokens.embeddings"), B, S, d, cfg.decoder_start_token_id)
+        ready("decoder.embed_tokens.embeddings")
 
         # ---- encoder backward
         dres = ws["dres_enc"]
         if cfg.decoder_layers == 0:
             d_enc.zero_()
         self._ln_bwd(d_enc, ws["enc_x"], "encoder.layer_norm", dres, "enc_ln", False)
+        ready("encoder.layer_norm.gamma")
         R = B * T
         for i in reversed(range(cfg.encoder_layers)):
             p, k = f"encoder.layers.{i}", f"enc{i}."
@@ -615,6 +631,7 @@ class WhisperForConditionalGeneration:
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+            ready(p + ".self_attn_layer_norm.gamma")
 
         # ---- stem backward: x0 = gelu(u2) + PE ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(x)
         du2pad, dh1pad = ws["du2pad"], ws["dh1pad"]
@@ -643,6 +660,7 @@ class WhisperForConditionalGeneration:
         gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
                  b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=0)
+        ready("encoder.conv1.kernel")
         return ws["loss"]
 
     def __call__(self, features, labels=None, training=True):
