@@ -49,7 +49,7 @@ const char* tmi_last_error(void);
  *   B(b,kb,k,n) = B[b*b_sb + kb*b_skb + k*b_sk + n*b_sn]
  *   C_b[m,n]    = C[b*c_sb + m*ldc + n]
  * epi(v), applied in this order:
- *   v += bias[n]                      (bias f32 [N] or NULL)
+ *   v += bias[b*bias_sb + n]          (bias f32 or NULL; bias_sb = 0 shares one bias over the batch)
  *   if n < scale_cols: v *= scale     (W:141: q = (xWq+b) * head_dim^-0.5)
  *   v += C_old                        (if accumulate != 0)
  *   if aux_out: aux_out[..] = v       (pre-activation saved for backward; layout as C)
@@ -70,7 +70,7 @@ typedef struct tmi_gemm_desc {
   int64_t a_sm, a_sk, b_sk, b_sn, ldc;
   int64_t nbatch, a_sb, b_sb, c_sb;
   int64_t kbatch, a_skb, b_skb;
-  const float* bias;
+  const float* bias; int64_t bias_sb;
   int64_t scale_cols; float scale;
   int32_t accumulate;
   int32_t act;
@@ -140,6 +140,7 @@ typedef struct tmi_attn_desc {
   int64_t do_sb, do_st, dq_sb, dq_st, dk_sb, dk_st, dv_sb, dv_st;
   float* delta;
   float dq_scale;              /* dq is multiplied by this on store (chain rule of W:141) */
+  float score_scale;           /* scores = (q . k) * score_scale (V:349 divides AFTER q.k^T); 0 means 1 */
 } tmi_attn_desc;
 int tmi_attn_fwd(const tmi_attn_desc* d, void* stream);
 int tmi_attn_bwd(const tmi_attn_desc* d, void* stream);
@@ -202,6 +203,73 @@ int tmi_feat_to_channels_last(const float* feats, void* out, int64_t B, int64_t 
 /* sum of squares of n fp32 values into out[0] (+= if accumulate): tf.clip_by_global_norm
  * (V:1243) first stage. */
 int tmi_sumsq(const float* x, float* out, int64_t n, int32_t accumulate, void* stream);
+
+/* ====================================================================================
+ * Wav2Vec2 pre-training path (speech_jobs/wav2vec2_dist.py, "V:")
+ * ==================================================================================== */
+
+/* GroupNormalization (V:140-196; contiguous channel groups, statistics over (time, C/G) per
+ * (batch, group), biased variance, per-channel affine) fused with the exact-erf GELU that
+ * follows it in every conv layer of the feature encoder (V:283-288):
+ *   y[b,t,c] = gelu(gamma[c] * (x - mean[b,g]) * rstd[b,g] + beta[c])
+ * x is [B][T][C] with batch stride x_sb, y likewise with y_sb (so y may be the padded input
+ * buffer of the next Conv1D).  stats: fp32 [B,G,2] = (mean, rstd), saved for backward.
+ * part: fp32 workspace [B * tmi_groupnorm_chunks(T) * G * 2].
+ * Backward: dx = d/dx of the above given dy (GELU' recomputed from x and stats);
+ * dgamma/dbeta are ACCUMULATED (atomics; caller zeroes); sums: fp32 workspace [B,G,2]. */
+int64_t tmi_groupnorm_chunks(int64_t T);
+int tmi_groupnorm_gelu_fwd(const void* x, int64_t x_sb, const float* gamma, const float* beta,
+                           void* y, int64_t y_sb, float* stats, float* part, int64_t B, int64_t T,
+                           int64_t C, int64_t G, float eps, int32_t dtype, void* stream);
+int tmi_groupnorm_gelu_bwd(const void* x, int64_t x_sb, const void* dy, int64_t dy_sb,
+                           const float* gamma, const float* beta, const float* stats, void* dx,
+                           int64_t dx_sb, float* dgamma, float* dbeta, float* part, float* sums,
+                           int64_t B, int64_t T, int64_t C, int64_t G, int32_t dtype, void* stream);
+
+/* Layout packs that turn the grouped positional Conv1D (V:271-277: k = 128, groups = 16,
+ * "same") into ONE batched tmi_gemm over overlapping rows:
+ *   tmi_group_pack:   x [B*T][C] -> xg [G][B*Tp][C/G], batch b's rows at [b*Tp + pad_left, +T),
+ *                     every other row zero (the "same" padding, and zero rows for the gradient);
+ *   tmi_group_unpack: out[b*T+t][g*Cg+j] = yg[g][b*Tp + t + row_off][j] (+ bias[c]) (+ resid);
+ *   tmi_posconv_pack_weights: Keras kernel w [k][C/G][C] fp32 -> forward operand
+ *                     wf[g][(kk,i)][o] = w[kk][i][g*Cg+o] and backward operand
+ *                     wb[g][(kk',o)][i] = w[k-1-kk'][i][g*Cg+o] (both [G][k*Cg][Cg], dtype). */
+int tmi_group_pack(const void* x, void* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t Tp,
+                   int64_t pad_left, int32_t dtype, void* stream);
+int tmi_group_unpack(const void* yg, const float* bias, const void* resid, void* out, int64_t B,
+                     int64_t T, int64_t C, int64_t G, int64_t Tp, int64_t row_off, int32_t dtype,
+                     void* stream);
+int tmi_posconv_pack_weights(const float* w, void* wf, void* wb, int64_t k, int64_t Cg, int64_t G,
+                             int32_t dtype, void* stream);
+
+/* Hard vector quantiser (V:581-667): per row and group, squared L2 to every code computed as
+ * sum((h-c)^2) in fp32, tf.argmin (first index on ties), q = the chosen code;
+ * perplexity[0] = mean_g exp(-sum_c p log(p+1e-10)), p = clip(mean one-hot, 1e-10, 1).
+ * h, q: [rows][G*gd] (dtype); codebook fp32 [G][Nc][gd]; idx int32 [rows][G].
+ * tmi_vq_bwd: dcodebook[g][idx][:] += dq (the only gradient path of the quantiser, V:638). */
+int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx, void* q, float* perplexity,
+                   int64_t rows, int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream);
+int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G,
+               int64_t Nc, int64_t gd, int32_t dtype, void* stream);
+
+/* Contrastive loss (V:866-899) on S [B][T][T] fp32 = all-pairs <h_t, q_t'> (a tmi_gemm):
+ * row (b,t) has logits [S[t][t], S[t][neg[b][0..Nn)]] / temperature and label 0;
+ * row_loss[b*T+t] = logsumexp - logit_0; S is REPLACED by d(sum row_loss)/dS * grad_scale. */
+int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, float* row_loss, int64_t B, int64_t T,
+                            int64_t Nn, float temperature, float grad_scale, void* stream);
+
+/* Gradient clipping.  seg_off: int64 device array [nseg+1] of element offsets into g.
+ * tmi_segment_sumsq: out[s] = sum g[seg_off[s]:seg_off[s+1]]^2.
+ * tmi_segment_clip:  g[seg s] *= clip / max(sqrt(sumsq[s]), clip).
+ * One segment covering the arena = tf.clip_by_global_norm (V:1243); one segment per variable
+ * = Keras clipnorm (V:1274). */
+int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* out, int64_t nseg, void* stream);
+int tmi_segment_clip(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,
+                     void* stream);
+
+/* out[0] = nan_to_zero(a[0] + w * b[0]) * scale  (V:1220-1231: contrastive + 0.1 * (-perplexity),
+ * NaN guard, / num_replicas) without a host round trip. */
+int tmi_loss_combine(const float* a, const float* b, float w, float scale, float* out, void* stream);
 
 #ifdef __cplusplus
 }

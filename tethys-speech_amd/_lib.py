@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("a_sm", c_i64), ("a_sk", c_i64), ("b_sk", c_i64), ("b_sn", c_i64), ("ldc", c_i64),
         ("nbatch", c_i64), ("a_sb", c_i64), ("b_sb", c_i64), ("c_sb", c_i64),
         ("kbatch", c_i64), ("a_skb", c_i64), ("b_skb", c_i64),
-        ("bias", c_vp),
+        ("bias", c_vp), ("bias_sb", c_i64),
         ("scale_cols", c_i64), ("scale", c_f32),
         ("accumulate", c_i32),
         ("act", c_i32),
@@ -46,6 +46,7 @@ class AttnDesc(C.Structure):
         ("dk_sb", c_i64), ("dk_st", c_i64), ("dv_sb", c_i64), ("dv_st", c_i64),
         ("delta", c_vp),
         ("dq_scale", c_f32),
+        ("score_scale", c_f32),
     ]
 
 
@@ -71,9 +72,21 @@ SIGNATURES = {
     "tmi_transpose_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_feat_to_channels_last": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_sumsq": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "tmi_groupnorm_chunks": (c_i64, [c_i64]),
+    "tmi_groupnorm_gelu_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_groupnorm_gelu_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_group_pack": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_group_unpack": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_posconv_pack_weights": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_vq_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_contrastive_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp]),
+    "tmi_segment_sumsq": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tmi_segment_clip": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "tmi_loss_combine": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 5
 _lib = None
 
 

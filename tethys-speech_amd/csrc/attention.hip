@@ -130,6 +130,7 @@ __device__ __forceinline__ void store_owner(const f32x16 (&y)[2], bf16_t* base, 
 struct AttnP {
   tmi_attn_desc d;
   float dq_scale;
+  float sscale;  // scores = (q . k) * sscale
 };
 
 #define ZERO2(y)                          \
@@ -180,13 +181,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP P) {
     for (int rbk = 0; rbk < 2; ++rbk) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float x = s[rbk][e];
+        float x = s[rbk][e] * P.sscale;
         if (edge) {
           const int key = key0 + 32 * rbk + acc_row(e, h);
           if (d.mask_mode == 1 && key <= q) x = x + (-1e9f);
           if (key >= Tk) x = -INFINITY;
-          s[rbk][e] = x;
         }
+        s[rbk][e] = x;
         mx = fmaxf(mx, x);
       }
     }
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
       f32x16 dp = first_product(Vimg, 32 * rbk, dof, c, h);  // dp[key][q]
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float x = s[e];
+        float x = s[e] * P.sscale;
         float p;
         if (edge) {
           const int key = key0 + 32 * rbk + acc_row(e, h);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnP P) {
     cur ^= 1;
   }
   bf16_t* dqb = reinterpret_cast<bf16_t*>(d.dq) + b * d.dq_sb + head * HD;
-  store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale);
+  store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale * P.sscale);
 }
 
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP P) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = 32 * rbk + acc_row(e, h);
-        float x = s[e];
+        float x = s[e] * P.sscale;
         float p;
         if (edge) {
           const int qi = q0 + r;
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnP P) {
   }
   bf16_t* dkb = reinterpret_cast<bf16_t*>(d.dk) + b * d.dk_sb + head * HD;
   bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
-  store_owner(dk, dkb, d.dk_st, key, Tk, h, 1.0f);
+  store_owner(dk, dkb, d.dk_st, key, Tk, h, P.sscale);
   store_owner(dv, dvb, d.dv_st, key, Tk, h, 1.0f);
 }
 
@@ -425,6 +426,7 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   AttnP P;
   P.d = *dp;
   P.dq_scale = 1.f;
+  P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
   dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
   return tmi_check_launch("tmi_attn_fwd");
@@ -439,6 +441,7 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   AttnP P;
   P.d = *dp;
   P.dq_scale = dp->dq_scale;
+  P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 gq((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 4 * IMG, s, P);

@@ -16,7 +16,7 @@ __device__ __forceinline__ void gemm_epilogue(const tmi_gemm_desc& d, f32x16 (&a
     for (int ni = 0; ni < 2; ++ni) {
       const int64_t n = n0 + wc * 64 + ni * 32 + c;
       if (n >= d.N) continue;
-      const float bv = d.bias ? d.bias[n] : 0.f;
+      const float bv = d.bias ? d.bias[bz * d.bias_sb + n] : 0.f;
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int64_t m = m0 + wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;

@@ -217,7 +217,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
   const bool full = P.wide && (n + 8 <= d.N);
   float bv[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[n + i] : 0.f;
+  for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[bz * d.bias_sb + n + i] : 0.f;
 #pragma unroll 1
   for (int p = 0; p < 8; ++p) {
     const int row = p * 8 + (lane >> 3);

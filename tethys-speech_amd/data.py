@@ -62,3 +62,29 @@ def create_dummy_dataset(batch_size, n_mels=80, seq_len=3000, max_target_length=
     """W:784 signature; ``batch_size`` is the PER-REPLICA batch (the reference passes the
     global batch and lets tf.distribute split it; rank/world are keyword arguments here)."""
     return DummyDataset(batch_size, n_mels, seq_len, max_target_length, **kw)
+
+
+class W2VDummyDataset:
+    """V:1123-1153: 50 x normal([32000]) fp32 clips (2 s at 16 kHz), labels unused,
+    ``batch(global_batch, drop_remainder=True).repeat()``; replica r takes rows
+    [r*B, (r+1)*B) of every global batch.  The pool is uploaded once."""
+
+    def __init__(self, batch_size, length=32000, device="cuda:0", rank=0, world=1, seed=1234, num_samples=50):
+        pool = np.random.default_rng(seed).standard_normal((num_samples, length)).astype(np.float32)
+        self.audio = torch.from_numpy(pool).to(device)
+        self.batch_size, self.rank, self.world = batch_size, rank, world
+        self.global_batch = batch_size * world
+        self.n = num_samples // self.global_batch * self.global_batch
+        if self.n == 0:
+            raise ValueError("global batch larger than the 50-clip pool")
+        self._pos = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._pos >= self.n:
+            self._pos = 0
+        s = self._pos + self.rank * self.batch_size
+        self._pos += self.global_batch
+        return self.audio[s:s + self.batch_size]

@@ -47,7 +47,7 @@ PROFILE = None  # set to a GemmProfile() to instrument
 
 
 def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
-         kbatch=1, a_skb=0, b_skb=0, bias=None, scale_cols=0, scale=1.0, accumulate=False,
+         kbatch=1, a_skb=0, b_skb=0, bias=None, bias_sb=0, scale_cols=0, scale=1.0, accumulate=False,
          act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
          a_off=0, b_off=0, c_off=0):
     """C = epi(A·B); see tmi_gemm in include/tethys_mi.h.  ``*_off`` are element offsets
@@ -62,6 +62,7 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     d.nbatch, d.a_sb, d.b_sb, d.c_sb = nbatch, a_sb, b_sb, c_sb
     d.kbatch, d.a_skb, d.b_skb = kbatch, a_skb, b_skb
     d.bias = ptr(bias)
+    d.bias_sb = bias_sb
     d.scale_cols, d.scale = scale_cols, scale
     d.accumulate = 1 if accumulate else 0
     d.act = act
@@ -130,7 +131,7 @@ def softmax_bwd(p, dp, rows, Tk):
     check(lib().tmi_softmax_bwd(p.data_ptr(), dp.data_ptr(), rows, Tk, stream()), "tmi_softmax_bwd")
 
 
-def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode):
+def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale=1.0):
     """q,k,v,o: (tensor, element_offset, batch_stride, token_stride)."""
     d = AttnDesc()
     for name, (t, off, sb, st) in (("q", q), ("k", k), ("v", v), ("o", o)):
@@ -140,16 +141,17 @@ def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode):
     d.stats = stats.data_ptr()
     d.B, d.H, d.Tq, d.Tk = B, H, Tq, Tk
     d.mask_mode = mask_mode
+    d.score_scale = score_scale
     return d
 
 
-def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0):
-    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode)
+def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0):
+    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
     check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
 
 
-def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0):
-    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode)
+def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0):
+    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
     for name, field, (t, off, sb, st) in (("d_o", "do", do), ("dq", "dq", dq), ("dk", "dk", dk), ("dv", "dv", dv)):
         setattr(d, name, t.data_ptr() + off * t.element_size())
         setattr(d, f"{field}_sb", sb)
@@ -200,3 +202,66 @@ def feat_to_channels_last(feats, out, B, Cn, T, pad_left, pad_right):
 
 def sumsq(x, out, n, accumulate=False):
     check(lib().tmi_sumsq(x.data_ptr(), out.data_ptr(), n, 1 if accumulate else 0, stream()), "tmi_sumsq")
+
+
+# ---------------------------------------------------------------- Wav2Vec2 operators
+def groupnorm_chunks(T: int) -> int:
+    return int(lib().tmi_groupnorm_chunks(T))
+
+
+def groupnorm_gelu_fwd(x, x_sb, gamma, beta, y, y_sb, stats, part, B, T, Cn, G, eps=1e-5, x_off=0, y_off=0):
+    check(lib().tmi_groupnorm_gelu_fwd(x.data_ptr() + x_off * x.element_size(), x_sb, gamma.data_ptr(), beta.data_ptr(),
+                                       y.data_ptr() + y_off * y.element_size(), y_sb, stats.data_ptr(), part.data_ptr(),
+                                       B, T, Cn, G, eps, dt(x), stream()), "tmi_groupnorm_gelu_fwd")
+
+
+def groupnorm_gelu_bwd(x, x_sb, dy, dy_sb, gamma, beta, stats, dx, dx_sb, dgamma, dbeta, part, sums, B, T, Cn, G,
+                       x_off=0, dy_off=0, dx_off=0):
+    es = x.element_size()
+    check(lib().tmi_groupnorm_gelu_bwd(x.data_ptr() + x_off * es, x_sb, dy.data_ptr() + dy_off * es, dy_sb,
+                                       gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                       dx.data_ptr() + dx_off * es, dx_sb, dgamma.data_ptr(), dbeta.data_ptr(),
+                                       part.data_ptr(), sums.data_ptr(), B, T, Cn, G, dt(x), stream()),
+          "tmi_groupnorm_gelu_bwd")
+
+
+def group_pack(x, xg, B, T, Cn, G, Tp, pad_left):
+    check(lib().tmi_group_pack(x.data_ptr(), xg.data_ptr(), B, T, Cn, G, Tp, pad_left, dt(x), stream()), "tmi_group_pack")
+
+
+def group_unpack(yg, bias, resid, out, B, T, Cn, G, Tp, row_off):
+    check(lib().tmi_group_unpack(yg.data_ptr(), ptr(bias), ptr(resid), out.data_ptr(), B, T, Cn, G, Tp, row_off,
+                                 dt(out), stream()), "tmi_group_unpack")
+
+
+def posconv_pack_weights(w, wf, wb, k, Cg, G, w_off=0):
+    check(lib().tmi_posconv_pack_weights(w.data_ptr() + 4 * w_off, wf.data_ptr(), wb.data_ptr(), k, Cg, G, dt(wf),
+                                         stream()), "tmi_posconv_pack_weights")
+
+
+def vq_nearest(h, codebook, idx, q, perplexity, rows, G, Nc, gd):
+    check(lib().tmi_vq_nearest(h.data_ptr(), codebook.data_ptr(), idx.data_ptr(), q.data_ptr(), perplexity.data_ptr(),
+                               rows, G, Nc, gd, dt(h), stream()), "tmi_vq_nearest")
+
+
+def vq_bwd(idx, dq, dcodebook, rows, G, Nc, gd):
+    check(lib().tmi_vq_bwd(idx.data_ptr(), dq.data_ptr(), dcodebook.data_ptr(), rows, G, Nc, gd, dt(dq), stream()),
+          "tmi_vq_bwd")
+
+
+def contrastive_fwd_bwd(S, neg, row_loss, B, T, Nn, temperature, grad_scale):
+    check(lib().tmi_contrastive_fwd_bwd(S.data_ptr(), neg.data_ptr(), row_loss.data_ptr(), B, T, Nn, temperature,
+                                        grad_scale, stream()), "tmi_contrastive_fwd_bwd")
+
+
+def segment_sumsq(g, seg_off, out, nseg):
+    check(lib().tmi_segment_sumsq(g.data_ptr(), seg_off.data_ptr(), out.data_ptr(), nseg, stream()), "tmi_segment_sumsq")
+
+
+def segment_clip(g, seg_off, sumsq, nseg, clip):
+    check(lib().tmi_segment_clip(g.data_ptr(), seg_off.data_ptr(), sumsq.data_ptr(), nseg, clip, stream()),
+          "tmi_segment_clip")
+
+
+def loss_combine(a, b, w, scale, out):
+    check(lib().tmi_loss_combine(a.data_ptr(), b.data_ptr(), w, scale, out.data_ptr(), stream()), "tmi_loss_combine")

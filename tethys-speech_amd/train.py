@@ -78,3 +78,76 @@ def load_checkpoint(model, optimizer, path):
     a.p.copy_(ck["p"]); a.m.copy_(ck["m"]); a.v.copy_(ck["v"])
     optimizer.iterations = int(ck["iterations"])
     model.refresh_shadows()
+
+
+# ---------------------------------------------------------------------------------------
+# Wav2Vec2 (speech_jobs/wav2vec2_dist.py, "V:")
+# ---------------------------------------------------------------------------------------
+def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
+    """V:1186-1260.  Per replica: forward, loss / num_replicas, backward, LOCAL
+    clip_by_global_norm(1.0) (V:1243, before the exchange), gradient all-reduce SUM (=> mean),
+    Keras clipnorm(1.0) per variable (V:1274, after aggregation), Adam; returns
+    strategy.reduce(SUM, scaled_loss)."""
+    from . import ops
+    a = model.arena
+    if audio.shape[0] > 0:
+        loss = model.forward_backward(audio, neg_indices, num_replicas=strategy.num_replicas_in_sync)
+    else:  # the reference's empty-batch branch (V:1196-1198, V:1250-1254)
+        a.g.zero_()
+        loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+    ws = model.ws
+    if audio.shape[0] > 0:
+        ops.segment_sumsq(a.g, model.seg_all, ws["clip_all"], 1)
+        ops.segment_clip(a.g, model.seg_all, ws["clip_all"], 1, 1.0)
+    strategy.all_reduce_gradients(a.g)
+    if audio.shape[0] > 0 or strategy.num_replicas_in_sync > 1:
+        model._prepare_clip()
+        ops.segment_sumsq(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var)
+        ops.segment_clip(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var, 1.0)
+    optimizer.apply_gradients(model, None)
+    model._pack_pos()
+    return strategy.reduce_sum(loss.clone())
+
+
+def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_epochs=1, learning_rate=3e-5, *,
+                   batch_size=1, num_batches=5, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print,
+                   seed=1234, clip_samples=32000, model_overrides=None):
+    """V:1263-1376: model + Adam(3e-5, eps 1e-8, clipnorm 1), 50 x 2 s dummy clips, per-step log
+    line, checkpoint every 50 steps and at the end."""
+    import numpy as np
+    from .data import W2VDummyDataset
+    from .wav2vec2 import create_full_model, sample_negative_indices
+    model = create_full_model(model_type, model_size, device=device, precision=precision, seed=seed,
+                              **(model_overrides or {}))
+    strategy.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    optimizer = Adam(learning_rate=learning_rate, epsilon=1e-8)
+    ds = W2VDummyDataset(batch_size, length=clip_samples, device=device, rank=strategy.rank, world=strategy.world, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    it = iter(ds)
+    step, losses = 0, []
+    start_time = time.time()
+    for epoch in range(num_epochs):
+        log(f"Epoch {epoch + 1}/{num_epochs}")
+        for _ in range(num_batches):
+            audio = next(it)
+            model._prepare(audio.shape[0], audio.shape[1])
+            # one draw per GLOBAL batch row, sliced per replica, so N replicas see what 1 would
+            neg_all = sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
+            neg = torch.from_numpy(neg_all[strategy.rank * batch_size:(strategy.rank + 1) * batch_size]).to(device)
+            step_start = time.time()
+            loss = wav2vec2_train_step(strategy, model, audio, neg, optimizer)
+            lv = float(loss.item())
+            step_end = time.time()
+            losses.append(lv)
+            log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
+                f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
+            step += 1
+            if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
+                os.makedirs(checkpoint_dir, exist_ok=True)
+                save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_step_{step}.pt"))
+        if checkpoint_dir and strategy.rank == 0:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_epoch_{epoch + 1}.pt"))
+    model.losses = losses
+    return model

@@ -1,0 +1,464 @@
+"""Wav2Vec2 pre-training step on the HIP kernels (host orchestration).
+
+Mirrors the reference's operator API for this path (speech_jobs/wav2vec2_dist.py, "V:"):
+``Wav2Vec2Config(model_size)`` (V:24-128), ``create_full_model("pretraining", model_size)``
+(V:1157-1182) and a model object whose ``forward_backward(audio, neg_indices)`` does what
+``model(features, training=True)`` + the loss assembly + ``tape.gradient`` do at V:1199-1240.
+Everything on the device is a C-ABI call from ``ops``; dropout rates are forced to 0 (no
+parity definition with TF's RNG).  The negative indices of V:908-937 are an input of the
+step (``sample_negative_indices`` draws them with the reference's recipe from a seeded
+generator).
+
+Layout notes: the q/k/v kernels of a layer are three separate contiguous [H, H] blocks (the
+projection is one batched GEMM), because Keras ``clipnorm`` (V:1274) clips every reference
+variable on its own; each conv layer writes its GroupNorm+GELU output straight into the
+padded buffer whose overlapping rows are the next Conv1D's im2col matrix; the grouped
+positional Conv1D runs as one batched window-GEMM over a group-major repack.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .blocks import Arena, KernelBlocks, _round_up
+from .whisper import same_pad
+
+
+@dataclass
+class Wav2Vec2Config:  # V:24-128 (fields read by the pre-training path)
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    conv_dim: Tuple[int, ...] = (512,) * 7
+    conv_stride: Tuple[int, ...] = (5, 2, 2, 2, 2, 2, 2)
+    conv_kernel: Tuple[int, ...] = (10, 3, 3, 3, 3, 2, 2)
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    num_codevectors_per_group: int = 320
+    num_codevector_groups: int = 2
+    codevector_dim: int = 256
+    proj_codevector_dim: int = 256
+    contrastive_logits_temperature: float = 0.1
+    num_negatives: int = 100
+    diversity_loss_weight: float = 0.1
+
+
+def make_config(model_size: str = "small", **overrides) -> Wav2Vec2Config:
+    if model_size == "small":
+        kw = dict(hidden_size=512, num_hidden_layers=6, num_attention_heads=8, intermediate_size=2048,
+                  conv_dim=(256,) * 5, conv_stride=(5, 2, 2, 2, 2), conv_kernel=(10, 3, 3, 3, 2),
+                  num_conv_pos_embeddings=64, num_conv_pos_embedding_groups=8,
+                  num_codevectors_per_group=160, codevector_dim=128, proj_codevector_dim=128)
+    elif model_size == "tiny":
+        kw = dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024,
+                  conv_dim=(128,) * 4, conv_stride=(5, 2, 2, 2), conv_kernel=(10, 3, 3, 2),
+                  num_conv_pos_embeddings=32, num_conv_pos_embedding_groups=4,
+                  num_codevectors_per_group=80, codevector_dim=64, proj_codevector_dim=64)
+    else:
+        kw = {}
+    kw.update(overrides)
+    return Wav2Vec2Config(**kw)
+
+
+def sample_negative_indices(rng: np.random.Generator, batch_size: int, T: int, num_negatives: int = 100) -> np.ndarray:
+    """V:908-937 -> [B, num_negatives] int32: the K = max(min(N, T-1), 1) positions with the
+    smallest uniform-int draws (top_k of the negated draws, lowest index first on ties),
+    repeated / truncated to N; the reference tiles them over every time step."""
+    K = max(min(num_negatives, T - 1), 1)
+    r = rng.integers(0, T, size=(batch_size, T))
+    order = np.argsort(r, axis=1, kind="stable")[:, :K]
+    if K < num_negatives:
+        order = np.tile(order, (1, -(-num_negatives // K)))
+    return order[:, :num_negatives].astype(np.int32)
+
+
+class W2VArena(Arena):
+    def __init__(self, cfg: Wav2Vec2Config, device):
+        H, I = cfg.hidden_size, cfg.intermediate_size
+        C, G = cfg.conv_dim[-1], cfg.num_conv_pos_embedding_groups
+        spec: List[Tuple[str, Tuple[int, ...]]] = []
+
+        def ln(p, n):
+            spec.extend([(f"{p}.gamma", (n,)), (f"{p}.beta", (n,))])
+
+        cin = 1
+        for i, (c, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
+            spec.append((f"feature_extractor.conv_layers.{i}.conv.kernel", (k, cin, c)))
+            ln(f"feature_extractor.conv_layers.{i}.norm", c)
+            cin = c
+        spec.append(("feature_extractor.pos_conv_embed.kernel", (cfg.num_conv_pos_embeddings, C // G, C)))
+        spec.append(("feature_extractor.pos_conv_embed.bias", (C,)))
+        ln("feature_extractor.layer_norm", C)
+        spec.extend([("feature_projection.kernel", (C, H)), ("feature_projection.bias", (H,))])
+        ln("feature_projection_layer_norm", H)
+        gd = cfg.codevector_dim // cfg.num_codevector_groups
+        spec.extend([("quantizer.projection.kernel", (H, cfg.codevector_dim)), ("quantizer.projection.bias", (cfg.codevector_dim,)),
+                     ("quantizer.codevectors", (cfg.num_codevector_groups, cfg.num_codevectors_per_group, gd))])
+        spec.extend([("project_q.dense.kernel", (cfg.codevector_dim, cfg.proj_codevector_dim)),
+                     ("project_q.dense.bias", (cfg.proj_codevector_dim,))])
+        ln("project_q.layer_norm", cfg.proj_codevector_dim)
+        for i in range(cfg.num_hidden_layers):
+            p = f"encoder.layers.{i}"
+            ln(f"{p}.attention_layer_norm", H)
+            spec.extend([(f"{p}.attention.qkv3.kernel", (3, H, H)), (f"{p}.attention.qkv3.bias", (3, H)),
+                         (f"{p}.attention.out_proj.kernel", (H, H)), (f"{p}.attention.out_proj.bias", (H,))])
+            ln(f"{p}.feed_forward_layer_norm", H)
+            spec.extend([(f"{p}.feed_forward.intermediate_dense.kernel", (H, I)), (f"{p}.feed_forward.intermediate_dense.bias", (I,)),
+                         (f"{p}.feed_forward.output_dense.kernel", (I, H)), (f"{p}.feed_forward.output_dense.bias", (H,))])
+        spec.extend([("project_hid.dense.kernel", (H, cfg.proj_codevector_dim)), ("project_hid.dense.bias", (cfg.proj_codevector_dim,))])
+        ln("project_hid.layer_norm", cfg.proj_codevector_dim)
+        super().__init__(spec, device)
+
+
+class Wav2Vec2ForPreTraining(KernelBlocks):
+    """V:826-937 (training path only)."""
+
+    def __init__(self, config: Wav2Vec2Config, device="cuda:0", precision: str = "bf16", seed: int = 1234):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        ops.lib()
+        self.config = config
+        self.device = torch.device(device)
+        self.precision = precision
+        self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.hidden = config.hidden_size
+        self.layer_norm_eps = config.layer_norm_eps
+        H = config.hidden_size
+        if H % config.num_attention_heads:
+            raise ValueError("hidden_size must divide by the head count")
+        if precision == "bf16" and H // config.num_attention_heads != 64:
+            raise ValueError("the fused attention kernel is built for head_dim 64")
+        if config.conv_dim[-1] % config.num_conv_pos_embedding_groups:
+            raise ValueError("conv_dim must divide by the group count")
+        self.arena = W2VArena(config, self.device)
+        self.arena.init_keras_defaults(seed)
+        self.ws: Dict[str, torch.Tensor] = {}
+        self._ws_key = None
+        self.mirror = None
+        if precision == "bf16":
+            self.mirror = torch.zeros(self.arena.numel, dtype=torch.bfloat16, device=self.device)
+        k, Cg = config.num_conv_pos_embeddings, config.conv_dim[-1] // config.num_conv_pos_embedding_groups
+        G = config.num_conv_pos_embedding_groups
+        self.pos_wf = torch.empty((G, k * Cg, Cg), dtype=self.dtype, device=self.device)
+        self.pos_wb = torch.empty_like(self.pos_wf)
+        segs = self.arena.variable_segments()
+        self.n_var = len(segs)
+        so = torch.tensor([s for s, _ in segs] + [segs[-1][1]], dtype=torch.int64)
+        # per-variable segments must tile [start, end) without gaps for the offset-array form;
+        # alignment padding between tensors belongs to the preceding variable's tail (zeros)
+        self.seg_vars = so.to(self.device)
+        self.seg_all = torch.tensor([0, self.arena.numel], dtype=torch.int64, device=self.device)
+        self.refresh_shadows()
+
+    def refresh_shadows(self):
+        super().refresh_shadows()
+        self._pack_pos()
+
+    def _prepare_clip(self):
+        if "clip_vars" not in self.ws:
+            self._buf("clip_vars", (self.n_var,), torch.float32)
+            self._buf("clip_all", (1,), torch.float32)
+
+    def _pack_pos(self):
+        cfg = self.config
+        G = cfg.num_conv_pos_embedding_groups
+        ops.posconv_pack_weights(self.arena.p, self.pos_wf, self.pos_wb, cfg.num_conv_pos_embeddings,
+                                 cfg.conv_dim[-1] // G, G, w_off=self.arena.offsets["feature_extractor.pos_conv_embed.kernel"])
+
+    # -- workspaces --------------------------------------------------------------------
+    def _prepare(self, B: int, T_in: int):
+        key = (B, T_in)
+        if self._ws_key == key:
+            return
+        self.ws.clear()
+        self._ws_key = key
+        cfg = self.config
+        f32 = torch.float32
+        L = len(cfg.conv_dim)
+        self.lens, self.pads = [], []
+        T = T_in
+        for k, s in zip(cfg.conv_kernel, cfg.conv_stride):
+            To, pl, pr = same_pad(T, k, s)
+            self.pads.append((pl, pr))
+            self.lens.append(To)
+            T = To
+        self.T = T
+        Gn = cfg.num_conv_pos_embedding_groups
+        slack = 2
+        z = dict(zero=True)
+        # input of conv layer i (padded, channels-last): i = 0 is the audio itself (C = 1)
+        self.Tp = [([T_in] + self.lens)[i] + self.pads[i][0] + self.pads[i][1] for i in range(L)]
+        self._buf("in0", (B, self.Tp[0] + slack + 8, 1), **z)
+        cin = 1
+        for i in range(L):
+            c = cfg.conv_dim[i]
+            self._buf(f"u{i}", (B, self.lens[i], c))
+            self._buf(f"gn{i}.stats", (B, Gn, 2), f32)
+            if i + 1 < L:
+                self._buf(f"in{i + 1}", (B, self.Tp[i + 1] + slack, c), **z)
+                self._buf(f"din{i + 1}", (B, self.Tp[i + 1] + slack, c), **z)
+            cin = c
+        C, H = cfg.conv_dim[-1], cfg.hidden_size
+        R = B * self.T
+        k = cfg.num_conv_pos_embeddings
+        Cg = C // Gn
+        self.plp, self.prp = same_pad(self.T, k, 1)[1:]
+        self.Tpp = self.T + k - 1            # forward geometry of the grouped conv
+        self.Tpp2 = self.T + 2 * (k - 1)     # gradient geometry (full correlation)
+        self._buf("h_last", (R, C))
+        self._buf("xg", (Gn, B * self.Tpp, Cg))
+        self._buf("yg", (Gn, B * self.Tpp, Cg))
+        self._buf("dyg", (Gn, B * self.Tpp, Cg))
+        self._buf("dyg2", (Gn, B * self.Tpp2, Cg))
+        self._buf("dxg2", (Gn, B * self.Tpp2, Cg))
+        self._buf("hp", (R, C))
+        self._buf("feats", (R, C))
+        self._buf("fe_ln.mean", (R,), f32); self._buf("fe_ln.rstd", (R,), f32)
+        self._buf("fp_pre", (R, H))
+        self._buf("fp_ln.mean", (R,), f32); self._buf("fp_ln.rstd", (R,), f32)
+        cd, pd = cfg.codevector_dim, cfg.proj_codevector_dim
+        self._buf("qin", (R, cd))
+        self._buf("quant", (R, cd))
+        self._buf("code_idx", (R, cfg.num_codevector_groups), torch.int32)
+        self._buf("perplexity", (1,), f32)
+        self._buf("pq_pre", (R, pd)); self._buf("pq", (R, pd))
+        self._buf("pq_ln.mean", (R,), f32); self._buf("pq_ln.rstd", (R,), f32)
+        self._buf("ph_pre", (R, pd)); self._buf("ph", (R, pd))
+        self._buf("ph_ln.mean", (R,), f32); self._buf("ph_ln.rstd", (R,), f32)
+        ff = cfg.intermediate_size
+        for i in range(cfg.num_hidden_layers):
+            p = f"enc{i}."
+            for n, shp in (("x_in", (R, H)), ("xn1", (R, H)), ("qkv", (R, 3 * H)), ("ctx", (R, H)), ("x_mid", (R, H)),
+                           ("xn2", (R, H)), ("u", (R, ff)), ("g", (R, ff))):
+                self._buf(p + n, shp)
+            for s_ in ("ln1", "ln2"):
+                self._buf(p + s_ + ".mean", (R,), f32); self._buf(p + s_ + ".rstd", (R,), f32)
+            if self.precision == "bf16":
+                self._buf(p + "stats", (B, cfg.num_attention_heads, self.T, 2), f32)
+            else:
+                self._buf(p + "P", (B, cfg.num_attention_heads, self.T, self.T), f32)
+        self._buf("enc_x", (R, H))
+        self._buf("S", (B, self.T, self.T), f32)
+        self._buf("dS", (B, self.T, self.T))
+        self._buf("row_loss", (R,), f32)
+        self._buf("closs", (1,), f32)
+        self._buf("loss", (1,), f32)
+        # backward scratch
+        self._buf("dres", (R, H)); self._buf("dtmp", (R, H)); self._buf("dctx", (R, H))
+        self._buf("dqkv", (R, 3 * H)); self._buf("dU", (R, ff))
+        self._buf("dph", (R, pd)); self._buf("dpq", (R, pd)); self._buf("dpd", (R, pd))
+        self._buf("dquant", (R, cd))
+        self._buf("dfeats", (R, C)); self._buf("dhp", (R, C)); self._buf("dh_last", (R, C))
+        if self.precision == "bf16":
+            self._buf("delta", (B, cfg.num_attention_heads, self.T), f32)
+        else:
+            self._buf("dP", (B, cfg.num_attention_heads, self.T, self.T), f32)
+        maxrows = max(1 + t for t in self.lens)
+        self._buf("dupad", (B * maxrows * max(cfg.conv_dim),), **z)
+        nch = max(ops.groupnorm_chunks(t) for t in self.lens)
+        self._buf("gn_part", (B * nch * Gn * 2,), f32)
+        self._buf("gn_sums", (B, Gn, 2), f32)
+        self._buf("clip_all", (1,), f32)
+        self._buf("clip_vars", (self.n_var,), f32)
+
+    # -- forward + backward ----------------------------------------------------------------
+    def forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
+        """One replica's V:1199-1240: returns the device scalar ``scaled_loss`` =
+        (contrastive + 0.1 * (-perplexity)) / num_replicas; gradients of it land in ``arena.g``."""
+        cfg = self.config
+        B, T_in = audio.shape
+        if audio.dtype != torch.float32 or neg_indices.dtype != torch.int32 or neg_indices.shape[0] != B:
+            raise TypeError("audio must be float32 [B, T] and neg_indices int32 [B, N]")
+        self._prepare(B, T_in)
+        ws, a = self.ws, self.arena
+        L = len(cfg.conv_dim)
+        Gn = cfg.num_conv_pos_embedding_groups
+        H, C = cfg.hidden_size, cfg.conv_dim[-1]
+        T, R = self.T, B * self.T
+        Hh = cfg.num_attention_heads
+        hd = H // Hh
+        sscale = 1.0 / math.sqrt(hd)
+        a.g.zero_()
+
+        # ---- feature encoder (V:283-288): conv -> GroupNorm -> GELU, 7 times
+        in0 = ws["in0"]
+        ops.feat_to_channels_last(audio, in0, B, 1, T_in, self.pads[0][0], in0.shape[1] - T_in - self.pads[0][0])
+        cin = 1
+        for i in range(L):
+            c, k, s = cfg.conv_dim[i], cfg.conv_kernel[i], cfg.conv_stride[i]
+            xin, u = ws[f"in{i}"], ws[f"u{i}"]
+            self._gemm_xw(xin, f"feature_extractor.conv_layers.{i}.conv.kernel", u, self.lens[i], c, k * cin, s * cin,
+                          ldc=c, nbatch=B, a_sb=xin.stride(0), c_sb=u.stride(0))
+            pre = f"feature_extractor.conv_layers.{i}.norm"
+            if i + 1 < L:
+                y, ysb, yoff = ws[f"in{i + 1}"], ws[f"in{i + 1}"].stride(0), self.pads[i + 1][0] * c
+            else:
+                y, ysb, yoff = ws["h_last"], self.lens[i] * c, 0
+            ops.groupnorm_gelu_fwd(u, u.stride(0), a.param(pre + ".gamma"), a.param(pre + ".beta"), y, ysb,
+                                   ws[f"gn{i}.stats"], ws["gn_part"], B, self.lens[i], c, Gn, 1e-5, y_off=yoff)
+            cin = c
+
+        # ---- grouped positional conv (V:271-277, V:291) as one batched window-GEMM
+        k = cfg.num_conv_pos_embeddings
+        Cg = C // Gn
+        h_last = ws["h_last"]
+        ops.group_pack(h_last, ws["xg"], B, T, C, Gn, self.Tpp, self.plp)
+        Mw = B * self.Tpp - (k - 1)
+        ops.gemm(ws["xg"], self.pos_wf, ws["yg"], Mw, Cg, k * Cg, Cg, 1, Cg, 1, Cg, nbatch=Gn,
+                 a_sb=B * self.Tpp * Cg, b_sb=k * Cg * Cg, c_sb=B * self.Tpp * Cg)
+        ops.group_unpack(ws["yg"], a.param("feature_extractor.pos_conv_embed.bias"), h_last, ws["hp"], B, T, C, Gn,
+                         self.Tpp, 0)
+        self._ln_fwd(ws["hp"], "feature_extractor.layer_norm", ws["feats"], "fe_ln")
+        self._dense_fwd(ws["feats"], "feature_projection.kernel", ws["fp_pre"])
+        hproj = ws["enc0.x_in"] if cfg.num_hidden_layers else ws["enc_x"]  # the encoder's input IS the projection
+        self._ln_fwd(ws["fp_pre"], "feature_projection_layer_norm", hproj, "fp_ln")
+
+        # ---- quantiser on the projected features (V:784): no gradient flows back through it
+        Gq, Nc = cfg.num_codevector_groups, cfg.num_codevectors_per_group
+        gd = cfg.codevector_dim // Gq
+        self._dense_fwd(hproj, "quantizer.projection.kernel", ws["qin"])
+        ops.vq_nearest(ws["qin"], a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R,
+                       Gq, Nc, gd)
+        self._dense_fwd(ws["quant"], "project_q.dense.kernel", ws["pq_pre"])
+        self._ln_fwd(ws["pq_pre"], "project_q.layer_norm", ws["pq"], "pq_ln")
+
+        # ---- encoder (V:419-439, stable layer norm)
+        for i in range(cfg.num_hidden_layers):
+            p, kk = f"encoder.layers.{i}", f"enc{i}."
+            x_in = ws[kk + "x_in"]
+            self._ln_fwd(x_in, p + ".attention_layer_norm", ws[kk + "xn1"], kk + "ln1")
+            wq, _ = self.W(p + ".attention.qkv3.kernel")  # [3H, H] view of the three blocks
+            ops.gemm(ws[kk + "xn1"], wq, ws[kk + "qkv"], R, H, H, H, 1, H, 1, 3 * H, nbatch=3, b_sb=H * H, c_sb=H,
+                     bias=a.param(p + ".attention.qkv3.bias"), bias_sb=H)
+            qkv = ws[kk + "qkv"]
+            self._attn_fwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
+                           ws[kk + "ctx"], B, Hh, T, T, 0, score_scale=sscale)
+            self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws[kk + "x_mid"], resid=x_in, r_ld=H)
+            self._ln_fwd(ws[kk + "x_mid"], p + ".feed_forward_layer_norm", ws[kk + "xn2"], kk + "ln2")
+            self._dense_fwd(ws[kk + "xn2"], p + ".feed_forward.intermediate_dense.kernel", ws[kk + "g"], act=1,
+                            aux_out=ws[kk + "u"])
+            nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.num_hidden_layers else ws["enc_x"]
+            self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", nxt, resid=ws[kk + "x_mid"], r_ld=H)
+
+        # ---- projection head + contrastive loss (V:550-561, V:866-899)
+        pd = cfg.proj_codevector_dim
+        self._dense_fwd(ws["enc_x"], "project_hid.dense.kernel", ws["ph_pre"])
+        self._ln_fwd(ws["ph_pre"], "project_hid.layer_norm", ws["ph"], "ph_ln")
+        S = ws["S"]
+        ops.gemm(ws["ph"], ws["pq"], S, T, T, pd, pd, 1, 1, pd, T, nbatch=B, a_sb=T * pd, b_sb=T * pd, c_sb=T * T)
+        Nn = neg_indices.shape[1]
+        inv_rep = 1.0 / num_replicas
+        ops.contrastive_fwd_bwd(S, neg_indices, ws["row_loss"], B, T, Nn, cfg.contrastive_logits_temperature,
+                                inv_rep / R)
+        ops.sum_scale(ws["row_loss"], ws["closs"], R, 1.0 / R)
+        ops.loss_combine(ws["closs"], ws["perplexity"], -cfg.diversity_loss_weight, inv_rep, ws["loss"])
+
+        # ================= backward =================
+        if self.precision == "bf16":
+            ops.cast_bf16(S, B * T * T, ws["dS"], B * T * T, 1, B * T * T)
+            dS = ws["dS"]
+        else:
+            dS = S
+        # d ph = dS · pq ; d pq = dSᵀ · ph   (per batch)
+        ops.gemm(dS, ws["pq"], ws["dph"], T, pd, T, T, 1, pd, 1, pd, nbatch=B, a_sb=T * T, b_sb=T * pd, c_sb=T * pd)
+        ops.gemm(dS, ws["ph"], ws["dpq"], T, pd, T, 1, T, pd, 1, pd, nbatch=B, a_sb=T * T, b_sb=T * pd, c_sb=T * pd)
+        # project_q branch -> codebook
+        self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd"], "pq_ln", False)
+        self._dense_bwd(ws["quant"], ws["dpd"], "project_q.dense.kernel", ws["dquant"])
+        ops.vq_bwd(ws["code_idx"], ws["dquant"], a.grad("quantizer.codevectors"), R, Gq, Nc, gd)
+        # project_hid branch -> encoder output
+        self._ln_bwd(ws["dph"], ws["ph_pre"], "project_hid.layer_norm", ws["dpd"], "ph_ln", False)
+        dres = ws["dres"]
+        self._dense_bwd(ws["enc_x"], ws["dpd"], "project_hid.dense.kernel", dres)
+
+        for i in reversed(range(cfg.num_hidden_layers)):
+            p, kk = f"encoder.layers.{i}", f"enc{i}."
+            dU, dt_, dctx, dqkv = ws["dU"], ws["dtmp"], ws["dctx"], ws["dqkv"]
+            self._dense_bwd(ws[kk + "g"], dres, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"])
+            self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_)
+            self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True)
+            self._dense_bwd(ws[kk + "ctx"], dres, p + ".attention.out_proj.kernel", dctx)
+            qkv = ws[kk + "qkv"]
+            self._attn_bwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
+                           ws[kk + "ctx"], dctx, (dqkv, 0), (dqkv, H), (dqkv, 2 * H), B, Hh, T, T, 0, score_scale=sscale,
+                           q_prescaled=False)
+            # three separate kernels: wgrad / bias grad batched over the blocks, dgrad summed over them
+            wq, _ = self.W(p + ".attention.qkv3.kernel")
+            gq = a.grad(p + ".attention.qkv3.kernel")
+            xn1 = ws[kk + "xn1"]
+            ops.gemm(xn1, dqkv, gq, H, H, R, 1, H, 3 * H, 1, H, nbatch=3, b_sb=H, c_sb=H * H, splitk=0)
+            ops.bias_grad(dqkv, a.grad(p + ".attention.qkv3.bias").view(3 * H))
+            ops.gemm(dqkv, wq, dt_, R, H, H, 3 * H, 1, 1, H, H, kbatch=3, a_skb=H, b_skb=H * H)
+            self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True)
+
+        # hproj feeds the encoder only (the quantiser branch is non-differentiable)
+        self._ln_bwd(dres, ws["fp_pre"], "feature_projection_layer_norm", ws["dtmp"], "fp_ln", False)
+        self._dense_bwd(ws["feats"], ws["dtmp"], "feature_projection.kernel", ws["dfeats"])
+        self._ln_bwd(ws["dfeats"], ws["hp"], "feature_extractor.layer_norm", ws["dhp"], "fe_ln", False)
+        dhp = ws["dhp"]
+        # hp = h_last + posconv(h_last) + bias
+        ops.bias_grad(dhp, a.grad("feature_extractor.pos_conv_embed.bias"))
+        ops.group_pack(dhp, ws["dyg"], B, T, C, Gn, self.Tpp, 0)
+        gwp = a.grad("feature_extractor.pos_conv_embed.kernel")
+        ops.gemm(ws["xg"], ws["dyg"], gwp, k * Cg, Cg, Mw, 1, Cg, Cg, 1, C, nbatch=Gn, a_sb=B * self.Tpp * Cg,
+                 b_sb=B * self.Tpp * Cg, c_sb=Cg, splitk=0)
+        ops.group_pack(dhp, ws["dyg2"], B, T, C, Gn, self.Tpp2, k - 1)
+        Mw2 = B * self.Tpp2 - (k - 1)
+        ops.gemm(ws["dyg2"], self.pos_wb, ws["dxg2"], Mw2, Cg, k * Cg, Cg, 1, Cg, 1, Cg, nbatch=Gn,
+                 a_sb=B * self.Tpp2 * Cg, b_sb=k * Cg * Cg, c_sb=B * self.Tpp2 * Cg)
+        ops.group_unpack(ws["dxg2"], None, dhp, ws["dh_last"], B, T, C, Gn, self.Tpp2, self.plp)
+
+        # ---- conv stack backward
+        for i in reversed(range(L)):
+            c, kc, s = cfg.conv_dim[i], cfg.conv_kernel[i], cfg.conv_stride[i]
+            cin = cfg.conv_dim[i - 1] if i else 1
+            Ti = self.lens[i]
+            pre = f"feature_extractor.conv_layers.{i}.norm"
+            u = ws[f"u{i}"]
+            if i + 1 < L:
+                dy, dysb, dyoff = ws[f"din{i + 1}"], ws[f"din{i + 1}"].stride(0), self.pads[i + 1][0] * c
+            else:
+                dy, dysb, dyoff = ws["dh_last"], Ti * c, 0
+            dup = ws["dupad"][:B * (1 + Ti) * c].view(B, 1 + Ti, c)  # row 0 of every batch stays zero
+            dup[:, 0].zero_()
+            ops.groupnorm_gelu_bwd(u, u.stride(0), dy, dysb, a.param(pre + ".gamma"), a.param(pre + ".beta"),
+                                   ws[f"gn{i}.stats"], dup, dup.stride(0), a.grad(pre + ".gamma"), a.grad(pre + ".beta"),
+                                   ws["gn_part"], ws["gn_sums"], B, Ti, c, Gn, dy_off=dyoff, dx_off=c)
+            wname = f"feature_extractor.conv_layers.{i}.conv.kernel"
+            xin = ws[f"in{i}"]
+            gw = a.grad(wname).view(kc * cin, c)
+            ops.gemm(xin, dup, gw, kc * cin, c, Ti, 1, s * cin, c, 1, c, kbatch=B, a_skb=xin.stride(0),
+                     b_skb=dup.stride(0), b_off=c, splitk=0)
+            if i == 0:
+                continue
+            if s != 2 or kc not in (2, 3):
+                raise NotImplementedError("conv dgrad is written for stride 2, kernel 2 or 3 (every reference size)")
+            w, ldw = self.W(wname)  # [kc*cin, c]
+            din = ws[f"din{i}"]
+            # even padded rows u = 2j: taps kk = 0 (t = j) and, for k = 3, kk = 2 (t = j - 1)
+            ops.gemm(dup, w, din, Ti, cin, c, c, 1, 1, ldw, 2 * cin, nbatch=B, a_sb=dup.stride(0), c_sb=din.stride(0),
+                     kbatch=2 if kc == 3 else 1, a_skb=-c, b_skb=2 * cin * ldw, a_off=c)
+            # odd padded rows u = 2j + 1: tap kk = 1
+            ops.gemm(dup, w, din, Ti, cin, c, c, 1, 1, ldw, 2 * cin, nbatch=B, a_sb=dup.stride(0), c_sb=din.stride(0),
+                     a_off=c, b_off=cin * ldw, c_off=cin)
+        return ws["loss"]
+
+    def __call__(self, inputs, neg_indices=None, training=True):
+        if not training or neg_indices is None:
+            raise NotImplementedError("only the training path is on the hot path")
+        return {"loss": self.forward_backward(inputs, neg_indices)}
+
+
+def create_full_model(model_type: str = "pretraining", model_size: str = "small", device="cuda:0",
+                      precision: str = "bf16", seed: int = 1234, **overrides) -> Wav2Vec2ForPreTraining:
+    """V:1157-1182; ``main`` hard-codes "pretraining" (V:1416), the only type on the hot path."""
+    if model_type != "pretraining":
+        raise NotImplementedError("only Wav2Vec2ForPreTraining is on the hot path (V:1416)")
+    return Wav2Vec2ForPreTraining(make_config(model_size, **overrides), device=device, precision=precision, seed=seed)

@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .blocks import Arena, KernelBlocks, _round_up
 
 
 # ----------------------------------------------------------------------------- config
@@ -88,12 +89,8 @@ def positional_encoding(max_len: int, d_model: int) -> np.ndarray:
     return pe.astype(np.float32)
 
 
-def _round_up(x: int, m: int) -> int:
-    return (x + m - 1) // m * m
-
-
 # ----------------------------------------------------------------------------- parameters
-class ParamArena:
+class ParamArena(Arena):
     """All trainable parameters in ONE flat fp32 buffer (plus same-shaped grad / Adam m / v
     buffers), in forward order so that backward fills the gradient arena from its end
     towards its start: all-reduce buckets are contiguous slices, ready in reverse order.
@@ -148,92 +145,11 @@ class ParamArena:
         spec.append(("lm_head.kernel", (d, self.v_pad)))
         self.logical: Dict[str, Tuple[int, ...]] = {"lm_head.kernel": (d, V)}
 
-        self.offsets: Dict[str, int] = {}
-        self.shapes: Dict[str, Tuple[int, ...]] = {}
-        off = 0
-        for name, shape in spec:
-            self.offsets[name] = off
-            self.shapes[name] = shape
-            off += _round_up(int(np.prod(shape)), 8)  # 16-byte alignment in the bf16 mirror too
-        self.numel = off
-        self.n_params = sum(int(np.prod(self.logical.get(n, s))) for n, s in self.shapes.items())
-        self.p = torch.zeros(off, dtype=torch.float32, device=device)
-        self.g = torch.zeros_like(self.p)
-        self.m = torch.zeros_like(self.p)
-        self.v = torch.zeros_like(self.p)
-        self.names = [n for n, _ in spec]
-
-    def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
-        o, s = self.offsets[name], self.shapes[name]
-        return buf[o:o + int(np.prod(s))].view(*s)
-
-    def param(self, name):
-        return self.view(self.p, name)
-
-    def grad(self, name):
-        return self.view(self.g, name)
-
-    def ref_views(self, buf: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Views of ``buf`` keyed by the reference's variable paths (oracle.param_shapes)."""
-        d = self.cfg.d_model
-        out: Dict[str, torch.Tensor] = {}
-        for name in self.names:
-            t = self.view(buf, name)
-            if name.endswith(".qkv.kernel"):
-                base = name[:-len("qkv.kernel")]
-                for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-                    out[f"{base}{n}.kernel"] = t[:, j * d:(j + 1) * d]
-            elif name.endswith(".qkv.bias"):
-                base = name[:-len("qkv.bias")]
-                for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
-                    out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
-            elif name.endswith(".kv.kernel"):
-                base = name[:-len("kv.kernel")]
-                for j, n in enumerate(("k_proj", "v_proj")):
-                    out[f"{base}{n}.kernel"] = t[:, j * d:(j + 1) * d]
-            elif name.endswith(".kv.bias"):
-                base = name[:-len("kv.bias")]
-                for j, n in enumerate(("k_proj", "v_proj")):
-                    out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
-            elif name in self.logical:
-                out[name] = t[tuple(slice(0, n) for n in self.logical[name])]
-            else:
-                out[name] = t
-        return out
-
-    def load_ref(self, params: Dict[str, torch.Tensor]):
-        """Copy a reference-keyed dict (e.g. the oracle's init_params) into the arena."""
-        views = self.ref_views(self.p)
-        missing = set(views) ^ set(params)
-        if missing:
-            raise KeyError(f"parameter name mismatch: {sorted(missing)[:4]} ...")
-        for k, v in views.items():
-            v.copy_(params[k].to(torch.float32))
-
-    def init_keras_defaults(self, seed: int = 1234):
-        """Keras default initialisers (SURVEY a-14): glorot-uniform kernels (per reference
-        tensor, so each fused q/k/v slice uses fan_in+fan_out of its own [d,d] kernel), zero
-        biases, Embedding U(-0.05, 0.05), LayerNorm gamma=1 / beta=0."""
-        gen = torch.Generator(device="cpu").manual_seed(seed)
-        for name, v in self.ref_views(self.p).items():
-            shape = tuple(v.shape)
-            if name.endswith(".kernel"):
-                if len(shape) == 3:
-                    fan_in, fan_out = shape[0] * shape[1], shape[0] * shape[2]
-                else:
-                    fan_in, fan_out = shape
-                lim = math.sqrt(6.0 / (fan_in + fan_out))
-                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * lim)
-            elif name.endswith(".embeddings"):
-                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * 0.05)
-            elif name.endswith(".gamma"):
-                v.fill_(1.0)
-            else:
-                v.zero_()
+        super().__init__(spec, device, logical=self.logical, fuse_width=d)
 
 
 # ----------------------------------------------------------------------------- model
-class WhisperForConditionalGeneration:
+class WhisperForConditionalGeneration(KernelBlocks):
     """W:536-616 (training path only).  Holds parameters, bf16 shadows and all activation
     workspaces; sized lazily for a batch size on first use."""
 
@@ -245,6 +161,8 @@ class WhisperForConditionalGeneration:
         self.device = torch.device(device)
         self.precision = precision
         self.dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.hidden = config.d_model
+        self.layer_norm_eps = config.layer_norm_eps
         self.arena = ParamArena(config, self.device)
         self.arena.init_keras_defaults(seed)
         d = config.d_model
@@ -266,34 +184,10 @@ class WhisperForConditionalGeneration:
             self.refresh_shadows()
 
     # -- weights ---------------------------------------------------------------------
-    def refresh_shadows(self):
-        """Re-derive the bf16 mirror from the fp32 master (after loading weights; the optimizer
-        step keeps it current by itself)."""
-        if self.precision != "bf16":
-            return
-        n = self.arena.numel
-        ops.cast_bf16(self.arena.p, n, self.mirror, n, 1, n)
 
-    def W(self, name) -> Tuple[torch.Tensor, int]:
-        """(2-D weight tensor [in, out], leading dimension) in the compute dtype."""
-        shape = self.arena.shapes[name]
-        rows = int(np.prod(shape[:-1]))
-        buf = self.mirror if self.precision == "bf16" else self.arena.p
-        return self.arena.view(buf, name).view(rows, shape[-1]), shape[-1]
 
-    def _gemm_xw(self, A, wname, Cm, M, N, K, a_sm, *, n_off=0, **kw):
-        """Cm = A · W[:, n_off:n_off+N] with W the natural [K, N_total] kernel (forward)."""
-        w, ldw = self.W(wname)
-        ops.gemm(A, w, Cm, M, N, K, a_sm, 1, ldw, 1, b_off=n_off, **kw)
 
     # -- workspaces --------------------------------------------------------------------
-    def _buf(self, name, shape, dtype=None, zero=False):
-        t = self.ws.get(name)
-        dtype = dtype or self.dtype
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self.ws[name] = t
-        return t
 
     def _prepare(self, B: int, T_in: int, S: int):
         key = (B, T_in, S)
@@ -382,97 +276,12 @@ class WhisperForConditionalGeneration:
             self._buf("dP", (B, max(He, Hd), max(self.T, S), self.T), f32)
 
     # -- building blocks -----------------------------------------------------------------
-    def _dense_fwd(self, x2d, wname, out2d, n_off=0, n_cols=None, **epi):
-        """out = x @ W[:, n_off:n_off+n_cols] (+bias ...).  W is the Keras [in, out] kernel."""
-        w, ldw = self.W(wname)
-        K = w.shape[0]
-        N = n_cols if n_cols is not None else self.arena.shapes[wname][-1]
-        bias = None
-        bname = wname.replace(".kernel", ".bias")
-        if bname in self.arena.offsets:
-            bias = self.arena.param(bname)[n_off:n_off + N]
-        self._gemm_xw(x2d, wname, out2d, x2d.shape[0], N, K, x2d.stride(0), ldc=out2d.stride(0), n_off=n_off,
-                      bias=bias, **epi)
 
-    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None):
-        """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in))."""
-        w, ldw = self.W(wname)
-        K_in = w.shape[0]
-        N = self.arena.shapes[wname][-1]
-        M = x2d.shape[0]
-        dW = self.arena.grad(wname).view(K_in, N)
-        ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N,
-                 splitk=0)
-        bname = wname.replace(".kernel", ".bias")
-        if bname in self.arena.offsets:
-            ops.bias_grad(dy2d, self.arena.grad(bname))
-        if dx2d is not None:
-            ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
-                     accumulate=accumulate_dx, aux_in=aux_in)
 
-    def _ln_fwd(self, x2d, pname, y2d, stat):
-        a = self.arena
-        ops.layernorm_fwd(x2d, a.param(pname + ".gamma"), a.param(pname + ".beta"), y2d,
-                          self.ws[stat + ".mean"], self.ws[stat + ".rstd"], self.config.layer_norm_eps)
 
-    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate):
-        a = self.arena
-        ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
-                          dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
 
     # attention: q/k/v given as (tensor2d, column offset); rows are (b, t) with Tq / Tk per batch
-    def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask):
-        d = self.config.d_model
-        (qt, qo), (kt, ko), (vt, vo) = q, k, v
-        if self.precision == "bf16":
-            ops.attn_fwd((qt, qo, Tq * qt.stride(0), qt.stride(0)), (kt, ko, Tk * kt.stride(0), kt.stride(0)),
-                         (vt, vo, Tk * vt.stride(0), vt.stride(0)), (ctx2d, 0, Tq * d, d),
-                         self.ws[key], B, H, Tq, Tk, mask)
-            return
-        P = self.ws[key]
-        hd = d // H
-        for b in range(B):
-            ops.gemm(qt, kt, P, Tq, Tk, hd, qt.stride(0), 1, 1, kt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd,
-                     c_sb=Tq * Tk, a_off=b * Tq * qt.stride(0) + qo, b_off=b * Tk * kt.stride(0) + ko,
-                     c_off=b * H * Tq * Tk)
-        ops.softmax_fwd(P, B * H * Tq, Tq, Tk, mask)
-        for b in range(B):
-            ops.gemm(P, vt, ctx2d, Tq, hd, Tk, Tk, 1, vt.stride(0), 1, d, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
-                     a_off=b * H * Tq * Tk, b_off=b * Tk * vt.stride(0) + vo, c_off=b * Tq * d)
 
-    def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask):
-        d = self.config.d_model
-        hd = d // H
-        scaling = hd ** -0.5
-        (qt, qo), (kt, ko), (vt, vo) = q, k, v
-        (dqt, dqo), (dkt, dko), (dvt, dvo) = dq, dk, dv
-        if self.precision == "bf16":
-            def m(t, off, T):
-                return (t, off, T * t.stride(0), t.stride(0))
-            ops.attn_bwd(m(qt, qo, Tq), m(kt, ko, Tk), m(vt, vo, Tk), m(ctx2d, 0, Tq), self.ws[key],
-                         m(dctx2d, 0, Tq), m(dqt, dqo, Tq), m(dkt, dko, Tk), m(dvt, dvo, Tk), self.ws["delta"],
-                         B, H, Tq, Tk, mask, dq_scale=scaling)
-            return
-        P = self.ws[key]
-        dP = self.ws["dP"]
-        for b in range(B):
-            po = b * H * Tq * Tk
-            # dP = dctx · Vᵀ
-            ops.gemm(dctx2d, vt, dP, Tq, Tk, hd, d, 1, 1, vt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd, c_sb=Tq * Tk,
-                     a_off=b * Tq * d, b_off=b * Tk * vt.stride(0) + vo, c_off=po)
-            # dV = Pᵀ · dctx
-            ops.gemm(P, dctx2d, dvt, Tk, hd, Tq, 1, Tk, d, 1, dvt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
-                     a_off=po, b_off=b * Tq * d, c_off=b * Tk * dvt.stride(0) + dvo)
-        ops.softmax_bwd(P, dP, B * H * Tq, Tk)
-        for b in range(B):
-            po = b * H * Tq * Tk
-            # dQ = dS · K  (then * scaling: chain rule of W:141, folded into this GEMM's column scale)
-            ops.gemm(dP, kt, dqt, Tq, hd, Tk, Tk, 1, kt.stride(0), 1, dqt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
-                     c_sb=hd, a_off=po, b_off=b * Tk * kt.stride(0) + ko, c_off=b * Tq * dqt.stride(0) + dqo,
-                     scale_cols=hd, scale=scaling)
-            # dK = dSᵀ · Q
-            ops.gemm(dP, qt, dkt, Tk, hd, Tq, 1, Tk, qt.stride(0), 1, dkt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
-                     c_sb=hd, a_off=po, b_off=b * Tq * qt.stride(0) + qo, c_off=b * Tk * dkt.stride(0) + dko)
 
     # -- forward -------------------------------------------------------------------------
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
