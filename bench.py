@@ -65,6 +65,54 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def bench_wav2vec2(args, strategy, dev, rank, world):
+    """Secondary workload (BASELINE configs[3]): Wav2Vec2-base pre-training step, 2 s clips."""
+    import numpy as np
+    import torch
+    from tethys_speech_amd import ops, optim, train, wav2vec2
+    from tethys_speech_amd.data import W2VDummyDataset
+    size = "base" if args.model_type == "small" else args.model_type
+    model = wav2vec2.create_full_model("pretraining", size, device=dev, precision=args.precision, seed=1234)
+    strategy.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
+    ds = W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234)
+    it = iter(ds)
+    rng = np.random.default_rng(1235)
+    negs = [torch.from_numpy(wav2vec2.sample_negative_indices(rng, args.batch_size, 100, 100)).to(dev)
+            for _ in range(args.steps + args.warmup)]
+
+    def one_step(i):
+        return train.wav2vec2_train_step(strategy, model, next(it), negs[i], opt)
+
+    for i in range(args.warmup):
+        one_step(i)
+    strategy.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    strategy.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log(f"wav2vec2-{size}: {dt / args.steps * 1e3:.2f} ms/step, loss {float(loss.item()):.4f}")
+    if rank == 0:
+        gb = args.batch_size * world
+        print(json.dumps({
+            "metric": "audio-seconds/sec/node (Wav2Vec2-base pretrain step, 2 s clips)", "value": 2.0 * gb * args.steps / dt,
+            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]",
+                       "global_batch": gb, "parallelism": f"dp{world}", "last_loss": float(loss.item())}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +121,8 @@ def main():
     ap.add_argument("--batch_size", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--model_type", default="small")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2"],
+                    help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -91,6 +141,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     strategy = D.DataParallelStrategy(rank, world, backend="nccl")
+    if args.workload == "wav2vec2":
+        return bench_wav2vec2(args, strategy, dev, rank, world)
 
     model = whisper.create_whisper_model(args.model_type, device=dev, precision=args.precision, seed=1234)
     strategy.broadcast_parameters(model.arena.p)

@@ -30,11 +30,29 @@ def tiny_curve(steps, seed=1234, dtype=torch.float64):
             "lr": 1e-4, "oracle_dtype": str(dtype), "losses": losses, "oracle_seconds": time.time() - t0}
 
 
+def w2v_curve(steps, model_size="base", seed=1234, dtype=torch.float64):
+    from oracle import wav2vec2_oracle as V
+    cfg = V.make_config(model_size)
+    params = {k: v.to(dtype) for k, v in V.init_params(cfg, seed=seed, dtype=torch.float32).items()}
+    pool = V.create_dummy_pool(seed=seed)
+    t0 = time.time()
+    losses, _ = V.train_steps(cfg, params, pool, 2, steps, seed=seed + 1, lr=3e-5)
+    return {"model": f"wav2vec2-{model_size} pretraining (V:24-128), 2 s clips", "batch_size": 2, "steps": steps,
+            "seed": seed, "neg_seed": seed + 1, "lr": 3e-5, "oracle_dtype": str(dtype), "losses": losses,
+            "oracle_seconds": time.time() - t0}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny-steps", type=int, default=10)
+    ap.add_argument("--only", choices=["whisper", "w2v", "all"], default="all")
     a = ap.parse_args()
     torch.set_num_threads(8)
-    out = tiny_curve(a.tiny_steps)
-    json.dump(out, open(os.path.join(HERE, "whisper_tiny_b2_10steps.json"), "w"), indent=1)
-    print(out)
+    if a.only in ("whisper", "all"):
+        out = tiny_curve(a.tiny_steps)
+        json.dump(out, open(os.path.join(HERE, "whisper_tiny_b2_10steps.json"), "w"), indent=1)
+        print(out)
+    if a.only in ("w2v", "all"):
+        out = w2v_curve(5)
+        json.dump(out, open(os.path.join(HERE, "wav2vec2_base_b2_5steps.json"), "w"), indent=1)
+        print(out)

@@ -182,3 +182,89 @@ def test_data_parallel_sum_semantics():
     # sum of two half-batch mean-loss gradients = 2 x gradient of the full-batch mean loss
     for k in ga:
         assert torch.allclose(ga[k] + gb[k], 2 * g1[k], rtol=1e-9, atol=1e-12)
+
+
+# ------------------------------------------------------------------ Wav2Vec2 oracle (V:)
+from oracle import wav2vec2_oracle as V2  # noqa: E402
+
+
+def test_w2v_parameter_counts_and_lengths():
+    assert V2.param_count(V2.make_config("base")) == 92_297_728
+    assert V2.param_count(V2.make_config("small")) == 20_466_816
+    assert V2.feature_lengths(V2.make_config("base"), 32000) == [6400, 3200, 1600, 800, 400, 200, 100]
+    assert V2.feature_lengths(V2.make_config("base"), 80000)[-1] == 250
+    assert V2.make_config("anything-else").hidden_size == 768  # V:49: the else branch is base
+
+
+def test_w2v_group_norm_hand_vector():
+    # B=1, T=2, C=4, G=2: group 0 = channels {0,1}, statistics over (time, 2 channels)
+    x = torch.tensor([[[1.0, 3.0, 10.0, 10.0], [5.0, 7.0, 10.0, 14.0]]])
+    y = V2.group_norm(x, torch.ones(4), torch.zeros(4), 2, eps=0.0)
+    g0 = (torch.tensor([1.0, 3.0, 5.0, 7.0]) - 4.0) / math.sqrt(5.0)
+    assert torch.allclose(y[0, :, :2].reshape(-1), g0[[0, 1, 2, 3]])
+    g1 = (torch.tensor([10.0, 10.0, 10.0, 14.0]) - 11.0) / math.sqrt(3.0)
+    assert torch.allclose(y[0, :, 2:].reshape(-1), g1)
+
+
+def test_w2v_negative_sampling_recipe():
+    rng = np.random.default_rng(0)
+    neg = V2.sample_negative_indices(rng, 4, 100, 100)
+    assert neg.shape == (4, 100) and neg.dtype == np.int32
+    for row in neg:
+        assert len(set(row[:99].tolist())) == 99          # K = T-1 distinct positions ...
+        assert row[99] == row[0]                            # ... tiled, then cut to 100 (V:924-929)
+    r = np.random.default_rng(0).integers(0, 100, size=(4, 100))
+    first = int(np.flatnonzero(r[0] == r[0].min())[0])      # smallest draw, lowest index on ties
+    assert neg[0, 0] == first
+    assert V2.sample_negative_indices(np.random.default_rng(1), 2, 250, 100).shape == (2, 100)  # K = 100 < T-1
+
+
+def _w2v_small():
+    cfg = V2.make_config("base", hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128,
+                         conv_dim=(32, 32, 32), conv_stride=(5, 2, 2), conv_kernel=(10, 3, 2),
+                         num_conv_pos_embeddings=8, num_conv_pos_embedding_groups=4, num_codevectors_per_group=16,
+                         codevector_dim=32, proj_codevector_dim=32, num_negatives=10)
+    pool = V2.create_dummy_pool(seed=1, num_samples=4, length=400)
+    neg = V2.sample_negative_indices(np.random.default_rng(0), 2, 20, 10)
+    return cfg, pool, neg
+
+
+def test_w2v_dead_gradients_and_loss_assembly():
+    cfg, pool, neg = _w2v_small()
+    p = V2.init_params(cfg, dtype=torch.float64)
+    loss, g, out = V2.loss_and_grads(p, torch.from_numpy(pool[:2]), torch.from_numpy(neg), cfg, num_replicas=2)
+    assert float(g["quantizer.projection.kernel"].abs().max()) == 0.0   # argmin/one-hot: no gradient (V:631-638)
+    assert float(g["quantizer.projection.bias"].abs().max()) == 0.0
+    assert float(g["quantizer.codevectors"].abs().max()) > 0.0
+    _, cl = V2.contrastive_loss(out["projected_states"], out["projected_quantized_features"], torch.from_numpy(neg), 0.1)
+    assert float(loss) == pytest.approx((float(cl) - 0.1 * float(out["codevector_perplexity"])) / 2, rel=1e-12)
+    assert 1.0 <= float(out["codevector_perplexity"]) <= 16.0
+
+
+def test_w2v_finite_differences_fp64():
+    cfg, pool, neg = _w2v_small()
+    p = V2.init_params(cfg, dtype=torch.float64)
+    a, n = torch.from_numpy(pool[:2]), torch.from_numpy(neg)
+    _, g, _ = V2.loss_and_grads(p, a, n, cfg)
+    for name in ["feature_extractor.conv_layers.0.conv.kernel", "feature_extractor.conv_layers.1.norm.gamma",
+                 "feature_extractor.pos_conv_embed.kernel", "encoder.layers.0.attention.k_proj.kernel",
+                 "project_q.dense.kernel", "quantizer.codevectors"]:
+        w, gi = p[name], g[name]
+        idx = tuple(torch.nonzero(gi.abs() > gi.abs().max() * 0.3)[0].tolist())
+        old, e = float(w[idx]), 1e-6
+        w[idx] = old + e
+        lp = float(V2.step_loss(p, a, n, cfg)[0])
+        w[idx] = old - e
+        lm = float(V2.step_loss(p, a, n, cfg)[0])
+        w[idx] = old
+        assert (lp - lm) / (2 * e) == pytest.approx(float(gi[idx]), rel=2e-5), name
+
+
+def test_w2v_clipping_rules():
+    g = {"a": torch.tensor([3.0, 4.0]), "b": torch.tensor([0.0, 12.0])}
+    c, n = V2.clip_by_global_norm(g, 1.0)
+    assert n == pytest.approx(13.0) and torch.allclose(c["a"], g["a"] / 13) and torch.allclose(c["b"], g["b"] / 13)
+    c, _ = V2.clip_by_global_norm({"a": torch.tensor([0.3, 0.4])}, 1.0)
+    assert torch.allclose(c["a"], torch.tensor([0.3, 0.4]))  # norm below the clip: untouched
+    e = V2.clip_by_norm_each(g, 1.0)
+    assert torch.allclose(e["a"], g["a"] / 5) and torch.allclose(e["b"], g["b"] / 12)

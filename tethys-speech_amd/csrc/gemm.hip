@@ -228,7 +228,16 @@ int launch(const tmi_gemm_desc& d, hipStream_t stream) {
   P.tiles_m = (int)((d.M + BM - 1) / BM);
   P.tiles_n = (int)((d.N + BN - 1) / BN);
   P.ktiles = (int)((d.K + BK - 1) / BK);
-  const int splitk = d.splitk > 1 ? d.splitk : 1;  // 0 (auto) means 1 on the generic path
+  int splitk = d.splitk > 1 ? d.splitk : 1;
+  if (d.splitk == 0 && sizeof(TC) == 4 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in && !d.resid &&
+      d.scale_cols <= 0) {  // auto split-K for weight-gradient shapes, as on the fast path
+    const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
+    const int64_t its = (int64_t)d.kbatch * P.ktiles;
+    int64_t want = (512 + tiles - 1) / tiles;
+    if (want > its / 4) want = its / 4;
+    if (want > 64) want = 64;
+    splitk = want < 1 ? 1 : (int)want;
+  }
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)d.nbatch);
   hipLaunchKernelGGL((gemm_kernel<T, TC>), grid, dim3(256), 2 * TILE_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm");

@@ -369,10 +369,17 @@ __global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restr
   __shared__ float red[4];
   const int s = blockIdx.x;
   const int64_t lo = seg_off[s], hi = seg_off[s + 1];
-  const int64_t n = hi - lo, per = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t n = hi - lo;
+  const int64_t per = ((n + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;  // whole float4s (segments start 16-B aligned)
   const int64_t a = lo + per * blockIdx.y, b = min(hi, a + per);
   float acc = 0.f;
-  for (int64_t i = a + threadIdx.x; i < b; i += 256) {
+  const bool vec = (lo & 3) == 0;
+  const int64_t nv = vec && b > a ? (b - a) / 4 : 0;
+  for (int64_t i = threadIdx.x; i < nv; i += 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(g + a)[i];
+    acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  for (int64_t i = a + nv * 4 + threadIdx.x; i < b; i += 256) {
     const float v = g[i];
     acc += v * v;
   }
@@ -387,9 +394,17 @@ __global__ __launch_bounds__(256) void segment_clip_kernel(float* __restrict__ g
   const int64_t lo = seg_off[s], hi = seg_off[s + 1];
   const float scale = clip / fmaxf(sqrtf(sumsq[s]), clip);
   if (scale == 1.0f) return;
-  const int64_t n = hi - lo, per = (n + gridDim.y - 1) / gridDim.y;
+  const int64_t n = hi - lo;
+  const int64_t per = ((n + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
   const int64_t a = lo + per * blockIdx.y, b = min(hi, a + per);
-  for (int64_t i = a + threadIdx.x; i < b; i += 256) g[i] *= scale;
+  const bool vec = (lo & 3) == 0;
+  const int64_t nv = vec && b > a ? (b - a) / 4 : 0;
+  for (int64_t i = threadIdx.x; i < nv; i += 256) {
+    f32x4 v = reinterpret_cast<f32x4*>(g + a)[i];
+    v *= scale;
+    reinterpret_cast<f32x4*>(g + a)[i] = v;
+  }
+  for (int64_t i = a + nv * 4 + threadIdx.x; i < b; i += 256) g[i] *= scale;
 }
 
 // out[0] = (isnan(a) ? 0 : a + w * b) * scale     (V:1220-1231: loss assembly on the device)
