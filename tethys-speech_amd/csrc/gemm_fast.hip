@@ -62,9 +62,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ---- KC staging: ROWS rows x 64 k (128 B per row); wave-instruction j covers rows 8j..8j+7
-template <int ROWS, int NW>
-__device__ __forceinline__ void stage_kc(char* lds, const bf16_t* base, int64_t s_row, int64_t row0, int64_t nrows,
-                                         int64_t k0, int wave, int lane) {
+// EM(src, i, j): what to do with wave-instruction j (the i-th of this wave) whose lane reads 16 B
+// at src: either issue the LDS-DMA to lds + j*1024 or load it into a register for a later
+// ds_write_b128 to lds + j*1024 + lane*16 (the same lane-linear image).
+template <int ROWS, int NW, typename EM>
+__device__ __forceinline__ void stage_kc(const bf16_t* base, int64_t s_row, int64_t row0, int64_t nrows,
+                                         int64_t k0, int wave, int lane, EM em) {
   constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -73,15 +76,32 @@ __device__ __forceinline__ void stage_kc(char* lds, const bf16_t* base, int64_t 
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     int64_t grow = row0 + r;
     grow = grow < nrows ? grow : nrows - 1;
-    glds16(base + grow * s_row + k0 + c * 8, lds + j * 1024);
+    em(base + grow * s_row + k0 + c * 8, i, j);
   }
 }
 
 // ---- KS staging: COLS/128 sub-images of [64 k-rows][128 cols] (256 B per row, 16 KiB each);
 // wave-instruction j covers k-rows 4(j%16)..+3 of sub-image j/16
-template <int COLS, int NW>
-__device__ __forceinline__ void stage_ks(char* lds, const bf16_t* base, int64_t s_k, int64_t col0, int64_t ncols_rd,
-                                         int64_t k0, int64_t kend, int wave, int lane) {
+// (COLS == 64: one [64 k-rows][64 cols] image, 128 B per row; wave-instruction j covers k-rows
+//  8j..8j+7, swizzle phys = chunk ^ (((k >> 1) & 1) << 2) — conflict-free for the transposed reads)
+template <int COLS, int NW, typename EM>
+__device__ __forceinline__ void stage_ks(const bf16_t* base, int64_t s_k, int64_t col0, int64_t ncols_rd,
+                                         int64_t k0, int64_t kend, int wave, int lane, EM em) {
+  if constexpr (COLS == 64) {
+    constexpr int PER64 = 8 / NW;
+#pragma unroll
+    for (int i = 0; i < PER64; ++i) {
+      const int j = PER64 * wave + i;
+      const int kr = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ (((kr >> 1) & 1) << 2);
+      int64_t gk = k0 + kr;
+      gk = gk < kend ? gk : kend - 1;
+      int64_t gc = col0 + c * 8;
+      gc = gc + 8 <= ncols_rd ? gc : ncols_rd - 8;
+      em(base + gk * s_k + gc, i, j);
+    }
+    return;
+  }
   constexpr int PER = COLS / 8 / NW;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
@@ -93,7 +113,7 @@ __device__ __forceinline__ void stage_ks(char* lds, const bf16_t* base, int64_t 
     gk = gk < kend ? gk : kend - 1;
     int64_t gc = col0 + sub * 128 + c * 8;
     gc = gc + 8 <= ncols_rd ? gc : ncols_rd - 8;
-    glds16(base + gk * s_k + gc, lds + j * 1024);
+    em(base + gk * s_k + gc, i, j);
   }
 }
 
@@ -102,7 +122,22 @@ __device__ __forceinline__ bf16x8 frag_kc(const char* tile, int row, int kk, int
   return *reinterpret_cast<const bf16x8*>(tile + row * 128 + off);
 }
 
+template <bool W64>
 __device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk, int lane) {
+  if constexpr (W64) {  // 128-byte-row image of a 64-column operand tile
+    const int g = lane >> 4, i = lane & 15;
+    const int h = g >> 1, q = i >> 2, p = i & 3;
+    const int col = col_base + 16 * (g & 1) + 4 * p;
+    bf16x4 part[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kr = 16 * kk + 8 * h + 4 * half + q;
+      const int chunk = (col >> 3) ^ (((kr >> 1) & 1) << 2);
+      const char* addr = tile + kr * 128 + chunk * 16 + (col & 7) * 2;
+      part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)addr);
+    }
+    return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
+  }
   // 32x32x16 operand fragment for k-step kk from a [k][col] image: lane (r, h) gets
   // T[16kk + 8h + j][col_base + r], j = 0..7, as two transposed 4x16 block reads.
   const int g = lane >> 4, i = lane & 15;
@@ -122,7 +157,7 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk
   return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool A_KS, bool B_KS, int MI, int NI>
+template <bool A_KS, bool B_KS, int MI, int NI, bool A64 = false, bool B64 = false>
 __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int row_base, int col_base, int lane,
                                          f32x16 (&acc)[MI][NI]) {
   const int r = lane & 31, h = lane >> 5;
@@ -131,12 +166,12 @@ __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int row
     bf16x8 a[MI], b[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      if constexpr (A_KS) a[i] = frag_ks(As, row_base + i * 32, kk, lane);
+      if constexpr (A_KS) a[i] = frag_ks<A64>(As, row_base + i * 32, kk, lane);
       else a[i] = frag_kc(As, row_base + i * 32 + r, kk, h);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if constexpr (B_KS) b[i] = frag_ks(Bs, col_base + i * 32, kk, lane);
+      if constexpr (B_KS) b[i] = frag_ks<B64>(Bs, col_base + i * 32, kk, lane);
       else b[i] = frag_kc(Bs, col_base + i * 32 + r, kk, h);
     }
 #pragma unroll
@@ -176,22 +211,19 @@ template <> struct Vec8<bf16_t> {
 
 __device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((col * 4) ^ ((row & 1) << 4)); }
 
-// One 64x64 piece of a wave's output (accumulator blocks a00 a01 / a10 a11) whose top-left element
-// is C[mw][nw]; E is the wave's private 16 KiB staging image.
+// One 32x64 piece of a wave's output (accumulator blocks a0 | a1) whose top-left element is
+// C[mw][nw]; E is the wave's private 8 KiB staging image.
 template <typename TC>
-__device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16& a00, const f32x16& a01,
-                                              const f32x16& a10, const f32x16& a11, char* E, int64_t mw, int64_t nw,
-                                              int64_t bz, int lane, bool atomic) {
+__device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16& a0, const f32x16& a1, char* E,
+                                              int64_t mw, int64_t nw, int64_t bz, int lane, bool atomic) {
   const tmi_gemm_desc& d = P.d;
   {
     const int c = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      *reinterpret_cast<float*>(E + epi_off(row, c)) = a00[reg];
-      *reinterpret_cast<float*>(E + epi_off(row, 32 + c)) = a01[reg];
-      *reinterpret_cast<float*>(E + epi_off(32 + row, c)) = a10[reg];
-      *reinterpret_cast<float*>(E + epi_off(32 + row, 32 + c)) = a11[reg];
+      *reinterpret_cast<float*>(E + epi_off(row, c)) = a0[reg];
+      *reinterpret_cast<float*>(E + epi_off(row, 32 + c)) = a1[reg];
     }
   }
   TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
@@ -199,7 +231,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
     if constexpr (sizeof(TC) == 4) {
       const int64_t n = nw + lane;
       if (n < d.N) {
-        for (int row = 0; row < 64; ++row) {
+        for (int row = 0; row < 32; ++row) {
           const int64_t m = mw + row;
           if (m >= d.M) break;
           atomicAdd(reinterpret_cast<float*>(C) + m * d.ldc + n, *reinterpret_cast<const float*>(E + epi_off(row, lane)));
@@ -219,7 +251,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
   for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[bz * d.bias_sb + n + i] : 0.f;
 #pragma unroll 1
-  for (int p = 0; p < 8; ++p) {
+  for (int p = 0; p < 4; ++p) {
     const int row = p * 8 + (lane >> 3);
     const int64_t m = mw + row;
     if (m >= d.M) continue;
@@ -275,6 +307,14 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
   }
 }
 
+__device__ unsigned long long g_gemm_stamps[8];  // diagnostics (ABL == 8): cycles per loop phase, block 0 wave 0
+
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // CFG 0: 128x128 tile, 4 waves (2x2) of 64x64, 2 stages (64 KiB, two workgroups per CU)
@@ -290,6 +330,23 @@ template <> struct Cfg<0> { static constexpr int BM = 128, BN = 128, WM = 64, WN
 template <> struct Cfg<1> { static constexpr int BM = 256, BN = 256, WM = 128, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
 template <> struct Cfg<2> { static constexpr int BM = 128, BN = 128, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = true; };
 template <> struct Cfg<3> { static constexpr int BM = 256, BN = 128, WM = 128, WN = 64, NSTAGE = 2; static constexpr bool SPEC = true; };
+// CFG 4 / 5: the same tiles with twice the waves (32x64 resp. 64x64 per wave): half the LDS-DMA
+// instructions per wave per K-tile, so their ~100-cycle issue cost stops dominating each wave's loop
+template <> struct Cfg<4> { static constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <> struct Cfg<5> { static constexpr int BM = 256, BN = 256, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+// CFG 6: 64x64 tile, 2 waves of 32x64 (32 KiB of LDS: several workgroups per CU).  For problems
+// with few 128x128 tiles (decoder / Wav2Vec2 encoder, M = B*100): a CU stages operands at
+// ~45 GB/s whatever the tile, so the time of such a GEMM is (BM + BN) * K * 2 B per workgroup
+// over that rate — smaller tiles on more CUs finish sooner.
+template <> struct Cfg<6> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+// CFG 7 / 8 / 9: tiles of CFG 4 / 5 / 6 with REGISTER staging (global_load_dwordx4 -> VGPR ->
+// ds_write_b128 into the same image): an LDS-DMA wave-instruction occupies the CU's memory
+// pipeline for ~55 cycles per KiB (measured with in-kernel stamps), which bounds a 128x128 tile
+// at ~0.8 PF/s; plain 16-byte loads issue several times faster
+template <> struct Cfg<7> { static constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <> struct Cfg<8> { static constexpr int BM = 256, BN = 256, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <> struct Cfg<9> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <int CFG> constexpr bool kRegStage = CFG >= 7;
 
 // ABL (diagnostics, compile-time so the production loop is untouched): 2 = no MFMA/fragment reads,
 // 4 = no staging after the prologue
@@ -339,14 +396,32 @@ void gemm_fast_kernel(const FastParams P) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto stage = [&](int it, int buf) {
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;  // wave-instructions per wave per tile
+  u32x4 ra[PA], rb[PB];                               // register staging only
+  auto walk = [&](int it, auto emA, auto emB) {
     const int kb = it / P.ktiles, kt = it - kb * P.ktiles;
+    if constexpr (A_KS) stage_ks<BM, NW>(Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 64, d.K, wave, lane, emA);
+    else stage_kc<BM, NW>(Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane, emA);
+    if constexpr (B_KS) stage_ks<BN, NW>(Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 64, d.K, wave, lane, emB);
+    else stage_kc<BN, NW>(Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane, emB);
+  };
+  auto stage = [&](int it, int buf) {  // LDS-DMA
     char* As = smem + buf * STAGE;
     char* Bs = As + A_BYTES;
-    if constexpr (A_KS) stage_ks<BM, NW>(As, Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
-    else stage_kc<BM, NW>(As, Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 64, wave, lane);
-    if constexpr (B_KS) stage_ks<BN, NW>(Bs, Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 64, d.K, wave, lane);
-    else stage_kc<BN, NW>(Bs, Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 64, wave, lane);
+    walk(it, [&](const bf16_t* src, int, int j) { glds16(src, As + j * 1024); },
+         [&](const bf16_t* src, int, int j) { glds16(src, Bs + j * 1024); });
+  };
+  auto fetch = [&](int it) {           // register staging, part 1: loads in flight
+    walk(it, [&](const bf16_t* src, int i, int) { ra[i] = *reinterpret_cast<const u32x4*>(src); },
+         [&](const bf16_t* src, int i, int) { rb[i] = *reinterpret_cast<const u32x4*>(src); });
+  };
+  auto commit = [&](int buf) {         // part 2: the same lane-linear image the DMA would write
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<u32x4*>(As + (PA * wave + i) * 1024 + lane * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<u32x4*>(Bs + (PB * wave + i) * 1024 + lane * 16) = rb[i];
   };
   // K tail (K % 64 != 0, host allows it only in (KS, KS)): rows k >= K of a KS image were loaded
   // from a clamped row; zero them so they contribute nothing
@@ -356,10 +431,17 @@ void gemm_fast_kernel(const FastParams P) {
       const int kvalid = (int)min((int64_t)64, d.K - (int64_t)kt * 64);
       if (kvalid < 64) {
         char* As = smem + buf * STAGE;
-        constexpr int NIMG = (BM + BN) / 128;  // consecutive 16 KiB [64][256 B] images: A sub-images, then B's
-        for (int idx = threadIdx.x; idx < NIMG * (64 - kvalid) * 16; idx += NTHREADS) {
-          const int img = idx / ((64 - kvalid) * 16), rem = idx % ((64 - kvalid) * 16);
-          *reinterpret_cast<u32x4*>(As + img * 16384 + kvalid * 256 + rem * 16) = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (BM == 64 && BN == 64) {  // two [64][128 B] images
+          for (int idx = threadIdx.x; idx < 2 * (64 - kvalid) * 8; idx += NTHREADS) {
+            const int img = idx / ((64 - kvalid) * 8), rem = idx % ((64 - kvalid) * 8);
+            *reinterpret_cast<u32x4*>(As + img * 8192 + kvalid * 128 + rem * 16) = u32x4{0u, 0u, 0u, 0u};
+          }
+        } else {
+          constexpr int NIMG = (BM + BN) / 128;  // consecutive 16 KiB [64][256 B] images: A sub-images, then B's
+          for (int idx = threadIdx.x; idx < NIMG * (64 - kvalid) * 16; idx += NTHREADS) {
+            const int img = idx / ((64 - kvalid) * 16), rem = idx % ((64 - kvalid) * 16);
+            *reinterpret_cast<u32x4*>(As + img * 16384 + kvalid * 256 + rem * 16) = u32x4{0u, 0u, 0u, 0u};
+          }
         }
         __syncthreads();
       }
@@ -367,6 +449,51 @@ void gemm_fast_kernel(const FastParams P) {
   };
 
   const bool stager = !K::SPEC || loader;
+  if constexpr (ABL == 8) {  // stamped copy of the loop: where do an iteration's cycles go?
+    unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+    if (nt > 0) {
+      stage(it0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int buf = 0;
+      for (int t = 0; t < nt; ++t) {
+        const unsigned long long t0 = stamp();
+        if (t + 1 < nt) stage(it0 + t + 1, buf ^ 1);
+        const unsigned long long t1 = stamp();
+        const char* As = smem + buf * STAGE;
+        mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+        asm volatile("s_nop 0" ::"v"(acc[0][0][0]));
+        const unsigned long long t2 = stamp();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = stamp();
+        __syncthreads();
+        const unsigned long long t4 = stamp();
+        acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += 1;
+        buf ^= 1;
+      }
+    }
+    if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+      for (int i = 0; i < 5; ++i) g_gemm_stamps[i] = acc_t[i];
+    wide_epilogue<TC>(P, acc[0][0], acc[0][1], smem + wave * 8192, m0 + wr * K::WM, n0 + wc * K::WN, bz, lane, false);
+    return;
+  }
+  if constexpr (kRegStage<CFG>) {
+    if (nt > 0) {
+      fetch(it0);
+      commit(0);
+      __syncthreads();
+      int buf = 0;
+      for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) fetch(it0 + t + 1);   // global loads fly under this tile's MFMAs
+        zero_tail(it0 + t, buf);
+        const char* As = smem + buf * STAGE;
+        mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+        if (t + 1 < nt) commit(buf ^ 1);      // nobody reads the other buffer during this iteration
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+  } else
   if (nt > 0) {
     if (stager) stage(it0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,7 +504,7 @@ void gemm_fast_kernel(const FastParams P) {
       zero_tail(it0 + t, buf);
       if (ABL != 2 && consumer) {
         const char* As = smem + buf * STAGE;
-        mma_tile<A_KS, B_KS, MI, NI>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+        mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -390,11 +517,10 @@ void gemm_fast_kernel(const FastParams P) {
     return;
   }
   static_assert(NI == 2, "epilogue pieces are 64 columns wide");
-  char* E = smem + wave * 16384;
+  char* E = smem + wave * 8192;
 #pragma unroll
-  for (int p = 0; p < MI / 2; ++p)
-    wide_epilogue<TC>(P, acc[2 * p][0], acc[2 * p][1], acc[2 * p + 1][0], acc[2 * p + 1][1], E,
-                      m0 + wr * K::WM + p * 64, n0 + wc * K::WN, bz, lane, nsplit > 1);
+  for (int p = 0; p < MI; ++p)
+    wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, nsplit > 1);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -405,7 +531,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   using K = Cfg<CFG>;
   constexpr int NW = (K::BM / K::WM) * (K::BN / K::WN);
   constexpr int LDS_BYTES = K::NSTAGE * (K::BM + K::BN) * 128;
-  static_assert(LDS_BYTES >= NW * 16384, "epilogue staging must fit the ring");
+  static_assert(LDS_BYTES >= NW * 8192, "epilogue staging must fit the ring");
   FastParams P;
   P.d = d;
   P.tiles_m = (int)((d.M + K::BM - 1) / K::BM);
@@ -419,10 +545,11 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
   auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
-  if constexpr (sizeof(TC) == 2 && !A_KS && CFG < 2) {  // ablation builds exist for the bf16-out KC-A kernels only
+  if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && (CFG < 2 || CFG == 4 || CFG == 6)) {  // ablation builds exist for the bf16-out KC-A kernels only
     if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
     if ((dbg & 6) == 4) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 4>;
-    if (dbg & 6) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (dbg == 8) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 8>;
+    if (dbg & 14) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<TC, A_KS, B_KS, CFG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -437,7 +564,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     // tile, one for the large), at least 4 K-tiles per split
     const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
     const int64_t its = (int64_t)d.kbatch * P.ktiles;
-    const int64_t slots = (CFG == 1 || CFG == 3) ? 256 : 512;
+    const int64_t slots = (CFG == 1 || CFG == 3 || CFG == 5 || CFG == 8) ? 256 : 512;
     int64_t want = (slots + tiles - 1) / tiles;
     if (want > its / 4) want = its / 4;
     if (want > 64) want = 64;
@@ -466,11 +593,25 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   // run better on the 128x128 tile with two workgroups per CU.
   const int64_t big_tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256) * d.nbatch;
   const double round_eff = (double)big_tiles / (double)(((big_tiles + 255) / 256) * 256);
+  const bool wgrad_like = d.splitk == 0 && d.out_dtype == TMI_F32;
   bool big = d.out_dtype == TMI_BF16 && d.M >= 2048 && d.N >= 512 && (d.K * d.kbatch >= 1536 || round_eff >= 0.8);
   if (force == 2) return launch_cfg<TC, A_KS, B_KS, 2>(d, stream);
   if (force == 3) return launch_cfg<TC, A_KS, B_KS, 3>(d, stream);
-  if (force >= 0) big = force == 1;
-  return big ? launch_cfg<TC, A_KS, B_KS, 1>(d, stream) : launch_cfg<TC, A_KS, B_KS, 0>(d, stream);
+  // too few 128x128 tiles to occupy the chip (and not a split-K weight gradient): 64x64 tiles
+  const int64_t mid_tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nbatch;
+  const bool small = !wgrad_like && mid_tiles < 200 && d.M >= 64 && d.N >= 64;
+  if (force == 0) return launch_cfg<TC, A_KS, B_KS, 0>(d, stream);
+  if (force == 1) return launch_cfg<TC, A_KS, B_KS, 1>(d, stream);
+  if (force == 2) return launch_cfg<TC, A_KS, B_KS, 2>(d, stream);
+  if (force == 3) return launch_cfg<TC, A_KS, B_KS, 3>(d, stream);
+  if (force == 4) return launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
+  if (force == 5) return launch_cfg<TC, A_KS, B_KS, 5>(d, stream);
+  if (force == 6) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  if (force == 7) return launch_cfg<TC, A_KS, B_KS, 7>(d, stream);
+  if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
+  if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
+  if (small) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
 }
 
 template <bool A_KS, bool B_KS>
@@ -479,6 +620,11 @@ int launch_out(const tmi_gemm_desc& d, hipStream_t stream) {
 }
 
 }  // namespace
+
+// diagnostics: copies the ABL == 8 phase counters (host-synchronous)
+extern "C" int tmi_debug_gemm_stamps(unsigned long long* out5) {
+  return hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_stamps), 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 
 // Returns 1 and sets *rc if the fast path took the GEMM, 0 if the generic kernel must run.
 int tmi_gemm_fast_try(const tmi_gemm_desc& d, hipStream_t stream, int* rc) {
