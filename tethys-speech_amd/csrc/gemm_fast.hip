@@ -560,12 +560,14 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   int splitk = d.splitk > 1 ? d.splitk : 1;
   if (d.splitk == 0 && d.out_dtype == TMI_F32 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in &&
       !d.resid && d.scale_cols <= 0) {
-    // auto split-K for weight-gradient shapes: fill the CUs (two workgroups each for the small
-    // tile, one for the large), at least 4 K-tiles per split
+    // auto split-K for weight-gradient shapes: as many splits as still fit ONE round of resident
+    // workgroups (two per CU for the small tile, one for the large) — one more would start a second,
+    // mostly empty round and add another pass of fp32 atomics; at least 4 K-tiles per split
     const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
     const int64_t its = (int64_t)d.kbatch * P.ktiles;
     const int64_t slots = (CFG == 1 || CFG == 3 || CFG == 5 || CFG == 8) ? 256 : 512;
-    int64_t want = (slots + tiles - 1) / tiles;
+    static const int ceil_mode = [] { const char* e = getenv("TMI_GEMM_SPLIT_CEIL"); return e ? atoi(e) : 0; }();
+    int64_t want = ceil_mode ? (slots + tiles - 1) / tiles : slots / tiles;
     if (want > its / 4) want = its / 4;
     if (want > 64) want = 64;
     splitk = want < 1 ? 1 : (int)want;

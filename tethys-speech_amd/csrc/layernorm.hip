@@ -4,32 +4,37 @@
 // 245,249,253,322,392 and its gradient.
 // Algorithmic bytes: fwd 2*n*s (+8 B/row stats), bwd 3*n*s (+ dgamma/dbeta partials).
 #include "tmi_common.h"
+#include <type_traits>
 
 namespace {
 
-constexpr int LN_E = 32;  // elements a lane can hold: C <= 64 * LN_E = 2048
+constexpr int LN_MAX_C = 2048;
 
-template <typename T>
+// A lane holds NCH 16-byte chunks of its row: chunk j covers columns (j*64 + lane)*VEC .. +VEC.
+// NCH is a template parameter so that a 768-wide row costs 2 chunks of registers, not the 4 (bf16)
+// or 8 (fp32) a 2048-wide one needs: the kernels are HBM-bound and live on waves in flight.
+template <typename T, int NCH_>
 struct RowIO {
   static constexpr int VEC = 16 / sizeof(T);
-  static constexpr int NCH = LN_E / VEC;  // chunks per lane
-  // chunk j of lane covers columns (j*64 + lane)*VEC .. +VEC
-  __device__ static __forceinline__ void load(const T* row, int C, int lane, float (&v)[LN_E]) {
+  static constexpr int NCH = NCH_;
+  static constexpr int E = NCH * VEC;
+  __device__ static __forceinline__ void load_raw(const T* row, int C, int lane, u32x4 (&raw)[NCH]) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c0 = (j * 64 + lane) * VEC;
-      if (c0 < C) {
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(row + c0);
-        const T* e = reinterpret_cast<const T*>(&raw);
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[j * VEC + i] = to_f32(e[i]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) v[j * VEC + i] = 0.f;
-      }
+      if (c0 < C) raw[j] = *reinterpret_cast<const u32x4*>(row + c0);
+      else raw[j] = u32x4{0u, 0u, 0u, 0u};
     }
   }
-  __device__ static __forceinline__ void store(T* row, int C, int lane, const float (&v)[LN_E]) {
+  __device__ static __forceinline__ void unpack(const u32x4 (&raw)[NCH], float (&v)[E]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const T* e = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[j * VEC + i] = to_f32(e[i]);
+    }
+  }
+  __device__ static __forceinline__ void store(T* row, int C, int lane, const float (&v)[E]) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c0 = (j * 64 + lane) * VEC;
@@ -41,7 +46,7 @@ struct RowIO {
       }
     }
   }
-  __device__ static __forceinline__ void load_f32vec(const float* p, int C, int lane, float (&v)[LN_E]) {
+  __device__ static __forceinline__ void load_f32vec(const float* p, int C, int lane, float (&v)[E]) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c0 = (j * 64 + lane) * VEC;
@@ -51,71 +56,107 @@ struct RowIO {
   }
 };
 
-template <typename T>
+// Each wave walks rows blockIdx*4 + wave, + gridDim*4, ... with the next row's 16-byte loads
+// issued before the current row is reduced.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int64_t rows, int C, float eps) {
-  using IO = RowIO<T>;
+  using IO = RowIO<T, NCH>;
+  constexpr int E = IO::E;
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t step = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  float v[LN_E], g[LN_E], b[LN_E];
-  IO::load(x + row * C, C, lane, v);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_E; ++i) s += v[i];
-  const float mu = wave_sum(s) / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < IO::NCH; ++j) {
-    const bool in = ((j * 64 + lane) * IO::VEC) < C;
-#pragma unroll
-    for (int i = 0; i < IO::VEC; ++i) {
-      const float dlt = in ? v[j * IO::VEC + i] - mu : 0.f;
-      q += dlt * dlt;
-    }
-  }
-  const float var = wave_sum(q) / (float)C;
-  const float rs = 1.0f / sqrtf(var + eps);
+  float g[E], b[E];
   IO::load_f32vec(gamma, C, lane, g);
   IO::load_f32vec(beta, C, lane, b);
+  const float invC = 1.0f / (float)C;
+  u32x4 nxt[NCH];
+  IO::load_raw(x + row * C, C, lane, nxt);
+  for (; row < rows; row += step) {
+    float v[E];
+    IO::unpack(nxt, v);
+    if (row + step < rows) IO::load_raw(x + (row + step) * C, C, lane, nxt);
+    float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_E; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
-  IO::store(y + row * C, C, lane, v);
-  if (lane == 0) {
-    mean[row] = mu;
-    rstd[row] = rs;
+    for (int i = 0; i < E; ++i) s += v[i];
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool in = ((j * 64 + lane) * IO::VEC) < C;
+#pragma unroll
+      for (int i = 0; i < IO::VEC; ++i) {
+        const float dlt = in ? v[j * IO::VEC + i] - mu : 0.f;
+        q += dlt * dlt;
+      }
+    }
+    const float var = wave_sum(q) * invC;
+    const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
+    IO::store(y + row * C, C, lane, v);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
   }
 }
 
-// Each wave walks rows blockIdx*4+wave, +gridDim*4, ...; dgamma/dbeta partials are folded over
-// the block's 4 waves in LDS and added to the fp32 gradient (zeroed by the caller) with one
-// atomic per column per block: 256 contiguous bytes per wave-instruction.
-template <typename T>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+// dgamma/dbeta partials are folded over the block's 8 waves through LDS slabs (LDS float atomics
+// measured 3x slower) and added to the fp32 gradient (zeroed by the caller) with one global atomic
+// per column per block.  Every block adds
+// to the same 2*C addresses, and same-address atomics serialise in L2 (measured: ~10 us per 512
+// blocks at C = 768), so the grid is kept to about one block per CU and each block starts its
+// column walk at a different offset.
+constexpr int LNB_WAVES = 8;
+template <typename T, int NCH>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C,
                                                      int accumulate_dx) {
-  using IO = RowIO<T>;
+  using IO = RowIO<T, NCH>;
+  constexpr int E = IO::E;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][C]
+  float* red = reinterpret_cast<float*>(smem);  // [8 waves][2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float g[LN_E], dg[LN_E], db[LN_E];
+  float g[E], dg[E], db[E];
   IO::load_f32vec(gamma, C, lane, g);
 #pragma unroll
-  for (int i = 0; i < LN_E; ++i) dg[i] = db[i] = 0.f;
+  for (int i = 0; i < E; ++i) dg[i] = db[i] = 0.f;
   const float invC = 1.0f / (float)C;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    float xv[LN_E], dv[LN_E];
-    IO::load(x + row * C, C, lane, xv);
-    IO::load(dy + row * C, C, lane, dv);
-    const float mu = mean[row], rs = rstd[row];
+  const int64_t step = (int64_t)gridDim.x * LNB_WAVES;
+  int64_t row = (int64_t)blockIdx.x * LNB_WAVES + wave;
+  u32x4 nx[NCH], ndy[NCH], nold[NCH];
+  float nmu = 0.f, nrs = 0.f;
+  if (row < rows) {
+    IO::load_raw(x + row * C, C, lane, nx);
+    IO::load_raw(dy + row * C, C, lane, ndy);
+    if (accumulate_dx) IO::load_raw(dx + row * C, C, lane, nold);
+    nmu = mean[row];
+    nrs = rstd[row];
+  }
+  for (; row < rows; row += step) {
+    float xv[E], dv[E], old[E];
+    IO::unpack(nx, xv);
+    IO::unpack(ndy, dv);
+    if (accumulate_dx) IO::unpack(nold, old);
+    const float mu = nmu, rs = nrs;
+    const int64_t nr = row + step;
+    if (nr < rows) {
+      IO::load_raw(x + nr * C, C, lane, nx);
+      IO::load_raw(dy + nr * C, C, lane, ndy);
+      if (accumulate_dx) IO::load_raw(dx + nr * C, C, lane, nold);
+      nmu = mean[nr];
+      nrs = rstd[nr];
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < IO::NCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const bool in = ((j * 64 + lane) * IO::VEC) < C;
 #pragma unroll
       for (int i = 0; i < IO::VEC; ++i) {
@@ -131,10 +172,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     s1 = wave_sum(s1) * invC;
     s2 = wave_sum(s2) * invC;
-    float old[LN_E];
-    if (accumulate_dx) IO::load(dx + row * C, C, lane, old);
 #pragma unroll
-    for (int e = 0; e < LN_E; ++e) {
+    for (int e = 0; e < E; ++e) {
       float r = rs * (dv[e] * g[e] - s1 - xv[e] * s2);
       if (accumulate_dx) r += old[e];
       dv[e] = r;
@@ -142,7 +181,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     IO::store(dx + row * C, C, lane, dv);
   }
 #pragma unroll
-  for (int j = 0; j < IO::NCH; ++j) {
+  for (int j = 0; j < NCH; ++j) {
     const int c0 = (j * 64 + lane) * IO::VEC;
     if (c0 < C) {
 #pragma unroll
@@ -153,15 +192,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int start = (int)((blockIdx.x * 64u) % (unsigned)C);
+  for (int i = threadIdx.x; i < C; i += 64 * LNB_WAVES) {
+    int c = start + i;
+    c = c >= C ? c - C : c;
     float a = 0.f, b = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < LNB_WAVES; ++w) {
       a += red[(w * 2 + 0) * C + c];
       b += red[(w * 2 + 1) * C + c];
     }
     atomicAdd(dgamma + c, a);
     atomicAdd(dbeta + c, b);
+  }
+}
+
+// chunk count for a row of C elements: smallest instantiated NCH that covers it
+template <typename T>
+inline int ln_nch(int64_t C) {
+  const int vec = 16 / (int)sizeof(T);
+  const int need = (int)((C + 64 * vec - 1) / (64 * vec));
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 8;
+}
+template <typename T, typename F>
+inline void ln_dispatch(int64_t C, F&& f) {
+  switch (ln_nch<T>(C)) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    default: f(std::integral_constant<int, 8>{}); break;
   }
 }
 
@@ -215,21 +275,29 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                  float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || C > 64 * LN_E || C % vec ||
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || C > LN_MAX_C || C % vec ||
       !al16(x) || !al16(y)) {
     tmi_set_error("tmi_layernorm_fwd: bad argument (C must be a multiple of 16 bytes and <= 2048)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
-                       mean, rstd, rows, (int)C, eps);
-  else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean,
-                       rstd, rows, (int)C, eps);
-  else
+  // whole rows per wave, at most ~1024 blocks of 4 waves (measured best on MI355X: 11.4 us for [12000, 768] bf16)
+  static const int64_t cap_f = [] { const char* e = getenv("TMI_LN_FWD_BLOCKS"); return e ? atoll(e) : 1024ll; }();
+  const int64_t rpw = (rows + 4 * cap_f - 1) / (4 * cap_f);
+  dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+  if (dtype == TMI_BF16) {
+    ln_dispatch<bf16_t>(C, [&](auto nch) {
+      hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, decltype(nch)::value>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
+                         (bf16_t*)y, mean, rstd, rows, (int)C, eps);
+    });
+  } else if (dtype == TMI_F32) {
+    ln_dispatch<float>(C, [&](auto nch) {
+      hipLaunchKernelGGL((ln_fwd_kernel<float, decltype(nch)::value>), grid, dim3(256), 0, s, (const float*)x, gamma, beta,
+                         (float*)y, mean, rstd, rows, (int)C, eps);
+    });
+  } else {
     return TMI_ERR_UNSUPPORTED;
+  }
   return tmi_check_launch("tmi_layernorm_fwd");
 }
 
@@ -237,23 +305,38 @@ extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gam
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                                  int32_t accumulate_dx, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > 64 * LN_E ||
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
       C % vec || !al16(x) || !al16(dy) || !al16(dx)) {
     tmi_set_error("tmi_layernorm_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  int64_t blocks = (rows + 7) / 8;  // two rows per wave: enough waves in flight to cover HBM latency
-  if (blocks > 2048) blocks = 2048;
-  const size_t lds = (size_t)8 * C * sizeof(float);
-  if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, s, (const bf16_t*)dy,
-                       (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx);
-  else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, s, (const float*)dy,
-                       (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx);
-  else
+  static const int64_t cap_b = [] { const char* e = getenv("TMI_LN_BWD_BLOCKS"); return e ? atoll(e) : 256ll; }();
+  int64_t rpw = (rows + LNB_WAVES * cap_b - 1) / (LNB_WAVES * cap_b);
+  if (rpw < 2) rpw = 2;  // amortise the per-block dgamma/dbeta fold
+  const int64_t blocks = (rows + LNB_WAVES * rpw - 1) / (LNB_WAVES * rpw);
+  const size_t lds = (size_t)LNB_WAVES * 2 * C * sizeof(float);  // <= 128 KiB at C = 2048
+  if (dtype == TMI_BF16) {
+    ln_dispatch<bf16_t>(C, [&](auto nch) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<bf16_t, decltype(nch)::value>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
+      (void)attr;
+      hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
+                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, rows, (int)C,
+                         accumulate_dx);
+    });
+  } else if (dtype == TMI_F32) {
+    ln_dispatch<float>(C, [&](auto nch) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<float, decltype(nch)::value>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
+      (void)attr;
+      hipLaunchKernelGGL((ln_bwd_kernel<float, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
+                         (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, (int)C,
+                         accumulate_dx);
+    });
+  } else {
     return TMI_ERR_UNSUPPORTED;
+  }
   return tmi_check_launch("tmi_layernorm_bwd");
 }
 

@@ -255,6 +255,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
         self._buf("dres_dec", (Rd, d))
         self._buf("d_enc_out", (R, d))
         self._buf("dtmp", (Rm, d))
+        if self.precision == "bf16":
+            self._buf("lmh_dx32", (Rd, d), f32)  # split-K accumulator of the LM-head dgrad
         self._buf("dctx", (Rm, d))
         self._buf("dqkv", (Rm, 3 * d))
         self._buf("dkvc", (R, 2 * d))
@@ -386,7 +388,14 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp, splitk=0)
         dtmp = ws["dtmp"][:B * S]
         # dgrad over the padded vocab (pad columns of dlogits are zero): a whole number of K tiles
-        ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
+        # (K = 51904 against only B*S x d outputs: in bf16 mode reduce it split-K into fp32 and round once)
+        if self.precision == "bf16":
+            acc = ws["lmh_dx32"]
+            acc.zero_()
+            ops.gemm(logits, wl, acc, B * S, d, Vp, Vp, 1, 1, ldw, d, splitk=0)
+            ops.cast_bf16(acc, d, dtmp, d, B * S, d)
+        else:
+            ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
         ready("decoder.layer_norm.gamma")
 
