@@ -557,30 +557,54 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     tmi_set_error("tmi_gemm(fast): cannot raise the dynamic LDS limit");
     return TMI_ERR_LAUNCH;
   }
-  int splitk = d.splitk > 1 ? d.splitk : 1;
-  if (d.splitk == 0 && d.out_dtype == TMI_F32 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in &&
-      !d.resid && d.scale_cols <= 0) {
-    // auto split-K for weight-gradient shapes: as many splits as still fit ONE round of resident
-    // workgroups (two per CU for the small tile, one for the large) — one more would start a second,
-    // mostly empty round and add another pass of fp32 atomics; at least 4 K-tiles per split
-    const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
-    const int64_t its = (int64_t)d.kbatch * P.ktiles;
-    const int64_t slots = (CFG == 1 || CFG == 3 || CFG == 5 || CFG == 8) ? 256 : 512;
-    static const int ceil_mode = [] { const char* e = getenv("TMI_GEMM_SPLIT_CEIL"); return e ? atoi(e) : 0; }();
-    int64_t want = ceil_mode ? (slots + tiles - 1) / tiles : slots / tiles;
-    if (want > its / 4) want = its / 4;
-    if (want > 64) want = 64;
-    splitk = want < 1 ? 1 : (int)want;
-  }
-  // choose the N split so one XCD's share of B (K x N/xn bf16) is <= ~2 MiB
+  // XCD partition: xn column groups x (8 / xn) row groups, one per XCD.  Aim for one XCD's share of
+  // B (K x N/xn bf16) <= ~2 MiB, but never pay for it with padding: among the four splits take the one
+  // with the fewest (padded) workgroups, nearest to the aimed one on ties.
   static const int force_xn = [] { const char* e = getenv("TMI_GEMM_XN"); return e ? atoi(e) : 0; }();
-  int xn = 1;
-  while (xn < 8 && (double)d.K * (double)d.kbatch * ((double)d.N / xn) * 2.0 > 2.0 * 1048576.0 && P.tiles_n >= 2 * xn) xn *= 2;
+  int aim = 1;
+  while (aim < 8 && (double)d.K * (double)d.kbatch * ((double)d.N / aim) * 2.0 > 2.0 * 1048576.0 && P.tiles_n >= 2 * aim) aim *= 2;
+  int xn = aim;
+  {
+    int64_t best = -1;
+    int best_dist = 0;
+    for (int cand = 1; cand <= 8; cand *= 2) {
+      const int64_t padded = (int64_t)((P.tiles_m + 8 / cand - 1) / (8 / cand)) * ((P.tiles_n + cand - 1) / cand);
+      int dist = 0;
+      for (int v = cand; v < aim; v *= 2) ++dist;
+      for (int v = aim; v < cand; v *= 2) ++dist;
+      if (best < 0 || padded < best || (padded == best && dist < best_dist)) {
+        best = padded;
+        best_dist = dist;
+        xn = cand;
+      }
+    }
+  }
   if (force_xn) xn = force_xn;
   P.xn = xn;
   P.xm = 8 / xn;
   P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
   P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  int splitk = d.splitk > 1 ? d.splitk : 1;
+  if (d.splitk == 0 && d.out_dtype == TMI_F32 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in &&
+      !d.resid && d.scale_cols <= 0) {
+    // Auto split-K for weight-gradient shapes (fp32 atomics into a zeroed C).  Measured on MI355X
+    // (tools/wgrad_bench.py): a split costs another pass of atomics over C at only ~0.5 TB/s, and
+    // splits beyond one resident round (two workgroups per CU for the small tiles, one for the large)
+    // do not shorten the K loop.  So: as many as fit one round, at most 5, at least 4 K-tiles each, and
+    // the total atomic traffic bounded by what the K loop can amortise (160 KB per K-tile + 3 MB).
+    const int64_t wgs = (int64_t)8 * P.ptm * P.ptn * d.nbatch;
+    const int64_t its = (int64_t)d.kbatch * P.ktiles;
+    const int64_t slots = (CFG == 1 || CFG == 3 || CFG == 5 || CFG == 8) ? 256 : 512;
+    const int64_t out_bytes = d.M * d.N * d.nbatch * 4;
+    int64_t want = slots / wgs;
+    if (want > 5) want = 5;
+    if (want > its / 4) want = its / 4;
+    const int64_t budget = its * 160 * 1024 + 3 * 1048576;
+    if (want > budget / out_bytes) want = budget / out_bytes;
+    static const int force_split = [] { const char* e = getenv("TMI_GEMM_SPLIT"); return e ? atoi(e) : 0; }();
+    if (force_split > 0) want = force_split < its ? force_split : its;
+    splitk = want < 1 ? 1 : (int)want;
+  }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
   hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm(fast)");
