@@ -225,19 +225,38 @@ inline void ln_dispatch(int64_t C, F&& f) {
   }
 }
 
+// Column sums (bias gradients).  A block owns 64 * VEC columns and a strided set of rows; its 8 waves
+// keep four 16-byte row loads in flight each, fold through LDS and add to `out` with one atomic per
+// column.  All blocks of a column group hit the same addresses and same-address atomics serialise in
+// L2 (~20 ns each), so the grid is ~one block per CU rather than thousands of small ones.
+constexpr int CS_WAVES = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
-                                                     int64_t rows, int64_t N) {
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
+                                                               int64_t rows, int64_t N) {
   constexpr int VEC = 16 / sizeof(T);
-  __shared__ float red[4][64 * VEC];
+  __shared__ float red[CS_WAVES][64 * VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
   float acc[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
   if (c0 < N) {
-    for (int64_t row = (int64_t)blockIdx.y * 4 + wave; row < rows; row += (int64_t)gridDim.y * 4) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(dy + row * ld + c0);
+    const int64_t step = (int64_t)gridDim.y * CS_WAVES;
+    int64_t row = (int64_t)blockIdx.y * CS_WAVES + wave;
+    const T* p = dy + row * ld + c0;
+    for (; row + 3 * step < rows; row += 4 * step, p += 4 * step * ld) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4*>(p + u * step * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* e = reinterpret_cast<const T*>(&raw[u]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += to_f32(e[i]);
+      }
+    }
+    for (; row < rows; row += step, p += step * ld) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
       const T* e = reinterpret_cast<const T*>(&raw);
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] += to_f32(e[i]);
@@ -246,9 +265,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, i
 #pragma unroll
   for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = acc[i];
   __syncthreads();
-  for (int c = threadIdx.x; c < 64 * VEC; c += 256) {
+  for (int c = threadIdx.x; c < 64 * VEC; c += 64 * CS_WAVES) {
     const int64_t n = (int64_t)blockIdx.x * 64 * VEC + c;
-    if (n < N) atomicAdd(out + n, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < CS_WAVES; ++w) a += red[w][c];
+    if (n < N) atomicAdd(out + n, a);
   }
 }
 
@@ -349,15 +371,16 @@ extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, 
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t xb = (N + 64 * vec - 1) / (64 * vec);
-  int64_t yb = (rows + 31) / 32;  // 8 rows per wave
-  const int64_t cap = (1024 + xb - 1) / xb;
+  static const int64_t cs_blocks = [] { const char* e = getenv("TMI_COLSUM_BLOCKS"); return e ? atoll(e) : 128ll; }();
+  int64_t yb = (rows + CS_WAVES * 4 - 1) / (CS_WAVES * 4);  // at least four rows per wave
+  const int64_t cap = (cs_blocks + xb - 1) / xb;
   if (yb > cap) yb = cap;
   if (yb < 1) yb = 1;
   dim3 grid((unsigned)xb, (unsigned)yb);
   if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, ld, out, rows, N);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64 * CS_WAVES), 0, s, (const bf16_t*)dy, ld, out, rows, N);
   else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, ld, out, rows, N);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64 * CS_WAVES), 0, s, (const float*)dy, ld, out, rows, N);
   else
     return TMI_ERR_UNSUPPORTED;
   return tmi_check_launch("tmi_colsum");
