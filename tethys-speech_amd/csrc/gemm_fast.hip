@@ -523,6 +523,202 @@ void gemm_fast_kernel(const FastParams P) {
     wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, nsplit > 1);
 }
 
+// =====================================================================================
+// 256x256 "eight-phase" kernel for (KC, KC) operands (dense dgrad: dX = dY . W^T).
+//
+// One workgroup per CU, 8 waves as 2 (wr) x 4 (wc), 128x64 outputs per wave = four 64x32
+// quadrants Q(a, b).  A K-tile (64) is four phases, one quadrant each (Q00, Q01, Q11, Q10: the A
+// fragments are reloaded once, B sub-block 0 is kept), and the loop body is two K-tiles = 8 phases
+// on an even/odd pair of LDS buffers.  LDS holds, per buffer, four 16 KiB half-tiles grouped by what
+// one phase reads: A^a = the a-th 64 rows of both wave rows, B^b = the b-th 32 columns of all four
+// wave columns.  Every phase stages ONE half-tile (two LDS-DMA per lane) two or more phases after
+// its last reader and three or more phases before its first, so the waits are counted
+// (vmcnt(6) / vmcnt(8), never 0 in the loop) and the DMA stays in flight across the barriers:
+//
+//   phase  stages                 reads (ds_read_b128)        waits      MFMAs
+//   1      O.B^1 <- tile 2i+1     E.A^0 (8), E.B^0 (4)                   Q00
+//   2      O.A^1 <- 2i+1          E.B^1 (4)                   vmcnt(8)   Q01
+//   3      E.B^0 <- 2i+2          E.A^1 (8)                              Q11
+//   4      E.A^0 <- 2i+2          -                           vmcnt(6)   Q10
+//   5      E.B^1 <- 2i+2          O.A^0 (8), O.B^0 (4)                   Q00
+//   6      E.A^1 <- 2i+2          O.B^1 (4)                   vmcnt(8)   Q01
+//   7      O.B^0 <- 2i+3          O.A^1 (8)                              Q11
+//   8      O.A^0 <- 2i+3          -                           vmcnt(6)   Q10
+//
+// A phase is  [reads, stage, wait] barrier [MFMAs at raised priority] barrier.  The wr = 1 waves
+// run one barrier behind the wr = 0 waves (they take one extra barrier on entry, the others one on
+// exit), so one group's MFMA section always coincides with the other's read/stage section.  A wait
+// in phase p covers reads from phase p + 1 on; restaging comes >= 2 phases after the last read: both
+// margins absorb the one-barrier stagger.  Stages past the last K-tile re-read the last tile (keeps
+// the counted waits exact); their data is never read.
+constexpr int P8_HALF = 16384, P8_BUF = 4 * P8_HALF;
+
+// LDS-DMA with a uniform 64-bit base and a per-lane 32-bit byte offset (the lane offsets are
+// loop-invariant: 8 VGPRs address all four half-tile kinds)
+__device__ __forceinline__ void glds16_so(const char* sbase, unsigned voff, char* lds_wave_base) {
+  const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_wave_base);
+  const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(dst_u)
+               : "memory");
+}
+
+__device__ __forceinline__ void p8_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename TC, bool B_KS>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][128 rows][128 B]
+  const tmi_gemm_desc& d = P.d;
+  const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+  const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
+  const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
+  if (tm >= P.tiles_m || tn >= P.tiles_n) return;
+  const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+  const int64_t bz = blockIdx.z;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int nt = P.ktiles;
+  const char* Abase = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + bz * d.a_sb);
+  const char* Bbase = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + bz * d.b_sb);
+
+  // ---- loop-invariant lane offsets of the staging loads: half-tile kind x wave-instruction
+  unsigned offA[2][2], offB[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ir = 8 * (2 * wave + i) + (lane >> 3);  // image row
+    const int c = (lane & 7) ^ ((ir >> 1) & 7);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int64_t gr = m0 + (ir >> 6) * 128 + 64 * a + (ir & 63);
+      gr = gr < d.M ? gr : d.M - 1;
+      offA[a][i] = (unsigned)((gr * d.a_sm + c * 8) * 2);
+      if constexpr (!B_KS) {
+        int64_t gc = n0 + (ir >> 5) * 64 + 32 * a + (ir & 31);
+        gc = gc < d.N ? gc : d.N - 1;
+        offB[a][i] = (unsigned)((gc * d.b_sn + c * 8) * 2);
+      } else {
+        // k-strided B: the half-tile is a [64 k][128 cols] image (256 B rows, stage_ks's swizzle); image
+        // columns 32w..32w+31 are tile columns 64w + 32b + (0..31)
+        const int kr = 4 * (2 * wave + i) + (lane >> 4);
+        const int cl = (lane & 15) ^ ((kr & 3) << 2);  // logical 8-column chunk this lane fetches
+        int64_t gc = n0 + ((8 * cl) >> 5) * 64 + 32 * a + ((8 * cl) & 31);
+        gc = gc + 8 <= P.b_cols_rd ? gc : P.b_cols_rd - 8;
+        offB[a][i] = (unsigned)((kr * d.b_sk + gc) * 2);
+      }
+    }
+  }
+  auto stage = [&](int buf, int kind, int kt) {  // kind: 0 A^0, 1 A^1, 2 B^0, 3 B^1
+    kt = kt < nt ? kt : nt - 1;
+    const char* src = kind < 2 ? Abase + (int64_t)kt * 128 : Bbase + (int64_t)kt * (B_KS ? 128 * d.b_sk : 128);
+    char* dst = smem + buf * P8_BUF + kind * P8_HALF + (2 * wave) * 1024;
+    const unsigned o0 = kind == 0 ? offA[0][0] : kind == 1 ? offA[1][0] : kind == 2 ? offB[0][0] : offB[1][0];
+    const unsigned o1 = kind == 0 ? offA[0][1] : kind == 1 ? offA[1][1] : kind == 2 ? offB[0][1] : offB[1][1];
+    glds16_so(src, o0, dst);
+    glds16_so(src, o1, dst + 1024);
+  };
+
+  // ---- fragment addresses: lane part is shared by A and B (same swizzle)
+  const int r = lane & 31, h = lane >> 5;
+  int xo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xo[kk] = r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4);
+  const int arow = wr * 64 * 128, brow = wc * 32 * 128;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  bf16x8 ar[2][4], b0[4], b1[4];
+
+  auto readA = [&](int bufoff, int a) {
+    const char* img = smem + bufoff + a * P8_HALF + arow;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = *reinterpret_cast<const bf16x8*>(img + mi * 4096 + xo[kk]);
+  };
+  auto readB = [&](int bufoff, int b, bf16x8 (&br)[4]) {
+    if constexpr (B_KS) {
+      const char* img = smem + bufoff + (2 + b) * P8_HALF;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) br[kk] = frag_ks<false>(img, 32 * wc, kk, lane);
+    } else {
+      const char* img = smem + bufoff + (2 + b) * P8_HALF + brow;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) br[kk] = *reinterpret_cast<const bf16x8*>(img + xo[kk]);
+    }
+  };
+#define P8_MMA(A_, B_, BR_)                                                                               \
+  do {                                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)     \
+        acc[2 * (A_) + mi][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[mi][kk], BR_[kk], acc[2 * (A_) + mi][B_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                        \
+  } while (0)
+
+  // ---- prologue: tile 0 whole, the first-read half of tile 1
+  stage(0, 2, 0);
+  stage(0, 0, 0);
+  stage(0, 3, 0);
+  stage(0, 1, 0);
+  stage(1, 2, 1);
+  stage(1, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  p8_barrier();
+  if (wr == 1) p8_barrier();  // this group runs one barrier behind
+
+  // one K-tile per iteration: phases 5..8 of the table are phases 1..4 with the buffers swapped
+  for (int t = 0; t < nt; ++t) {
+    const int own = t & 1, oth = own ^ 1;
+    const int ownoff = own * P8_BUF;
+    readB(ownoff, 0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    readA(ownoff, 0);
+    stage(oth, 3, t + 1);
+    p8_barrier();
+    P8_MMA(0, 0, b0);
+    p8_barrier();
+
+    readB(ownoff, 1, b1);
+    stage(oth, 1, t + 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    p8_barrier();
+    P8_MMA(0, 1, b1);
+    p8_barrier();
+
+    readA(ownoff, 1);
+    stage(own, 2, t + 2);
+    p8_barrier();
+    P8_MMA(1, 1, b1);
+    p8_barrier();
+
+    stage(own, 0, t + 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    p8_barrier();
+    P8_MMA(1, 0, b0);
+    p8_barrier();
+  }
+#undef P8_MMA
+  if (wr == 0) p8_barrier();  // rejoin the other group
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages must land before LDS is reused
+  p8_barrier();
+
+  char* E = smem + wave * 8192;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+    wide_epilogue<TC>(P, acc[mi][0], acc[mi][1], E, m0 + wr * 128 + mi * 32, n0 + wc * 64, bz, lane, false);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t rup8(int64_t x) { return (x + 7) / 8 * 8; }
 
@@ -610,6 +806,60 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   return tmi_check_launch("tmi_gemm(fast)");
 }
 
+// eight-phase kernel: (KC, KC), one K batch, no split-K, operand spans addressable with 32-bit byte offsets
+inline bool p8_eligible(const tmi_gemm_desc& d, bool b_ks) {
+  const double a_span = ((double)(d.M - 1) * (double)d.a_sm + (double)d.K) * 2.0;
+  const double b_span = b_ks ? ((double)(d.K - 1) * (double)d.b_sk + (double)d.N + 8.0) * 2.0
+                             : ((double)(d.N - 1) * (double)d.b_sn + (double)d.K) * 2.0;
+  return d.kbatch == 1 && d.splitk <= 1 && d.K % 64 == 0 && d.K >= 128 && d.a_sm >= 0 && d.b_sn >= 0 && a_span < 4.0e9 &&
+         b_span < 4.0e9;
+}
+
+template <typename TC, bool B_KS>
+int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
+  FastParams P;
+  P.d = d;
+  P.tiles_m = (int)((d.M + 255) / 256);
+  P.tiles_n = (int)((d.N + 255) / 256);
+  P.ktiles = (int)(d.K / 64);
+  P.a_cols_rd = 0;
+  P.b_cols_rd = rup8(d.N);
+  const int vecC = 16 / (int)sizeof(TC);
+  P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
+           (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
+  P.dbg = 0;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, B_KS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
+  if (attr != hipSuccess) {
+    tmi_set_error("tmi_gemm(p8): cannot raise the dynamic LDS limit");
+    return TMI_ERR_LAUNCH;
+  }
+  // XCD partition with the fewest padded workgroups (see launch_cfg)
+  int aim = 1;
+  while (aim < 8 && (double)d.K * ((double)d.N / aim) * 2.0 > 2.0 * 1048576.0 && P.tiles_n >= 2 * aim) aim *= 2;
+  int xn = aim;
+  int64_t best = -1;
+  int best_dist = 0;
+  for (int cand = 1; cand <= 8; cand *= 2) {
+    const int64_t padded = (int64_t)((P.tiles_m + 8 / cand - 1) / (8 / cand)) * ((P.tiles_n + cand - 1) / cand);
+    int dist = 0;
+    for (int v = cand; v < aim; v *= 2) ++dist;
+    for (int v = aim; v < cand; v *= 2) ++dist;
+    if (best < 0 || padded < best || (padded == best && dist < best_dist)) {
+      best = padded;
+      best_dist = dist;
+      xn = cand;
+    }
+  }
+  P.xn = xn;
+  P.xm = 8 / xn;
+  P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
+  P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  dim3 grid((unsigned)(8 * P.ptm * P.ptn), 1, (unsigned)d.nbatch);
+  hipLaunchKernelGGL((gemm_p8_kernel<TC, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, P);
+  return tmi_check_launch("tmi_gemm(p8)");
+}
+
 template <typename TC, bool A_KS, bool B_KS>
 int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int force = [] { const char* e = getenv("TMI_GEMM_CFG"); return e ? atoi(e) : -1; }();
@@ -621,8 +871,9 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   const double round_eff = (double)big_tiles / (double)(((big_tiles + 255) / 256) * 256);
   const bool wgrad_like = d.splitk == 0 && d.out_dtype == TMI_F32;
   bool big = d.out_dtype == TMI_BF16 && d.M >= 2048 && d.N >= 512 && (d.K * d.kbatch >= 1536 || round_eff >= 0.8);
-  if (force == 2) return launch_cfg<TC, A_KS, B_KS, 2>(d, stream);
-  if (force == 3) return launch_cfg<TC, A_KS, B_KS, 3>(d, stream);
+  if constexpr (!A_KS) {
+    if (force == 10 && p8_eligible(d, B_KS)) return launch_p8<TC, B_KS>(d, stream);
+  }
   // too few 128x128 tiles to occupy the chip (and not a split-K weight gradient): 64x64 tiles
   const int64_t mid_tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nbatch;
   const bool small = !wgrad_like && mid_tiles < 200 && d.M >= 64 && d.N >= 64;
@@ -637,6 +888,16 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
   if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
   if (small) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py): +20 % on long reductions; with a
+  // k-strided B and a short K its un-overlapped epilogue (one workgroup per CU) loses to the two
+  // co-resident 128x128 workgroups, so those stay where they were.
+  if constexpr (!A_KS) {
+    static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
+    const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
+    if (!no_p8 && force < 0 && !wgrad_like && p8_eligible(d, B_KS) && d.M >= 2048 && d.N >= 256 &&
+        (d.K >= 1536 || (!B_KS && light_epi)))
+      return launch_p8<TC, B_KS>(d, stream);
+  }
   return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
 }
 
