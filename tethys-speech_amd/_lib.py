@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("resid", c_vp), ("r_ld", c_i64), ("r_sb", c_i64),
         ("splitk", c_i32),
         ("in_dtype", c_i32), ("out_dtype", c_i32),
+        ("workspace", c_vp), ("workspace_bytes", c_i64),
     ]
 
 
@@ -86,7 +87,7 @@ SIGNATURES = {
     "tmi_loss_combine": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _lib = None
 
 

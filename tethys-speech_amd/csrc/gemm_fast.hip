@@ -53,6 +53,9 @@ struct FastParams {
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
   int dbg;           // TMI_GEMM_DBG bit 1 (diagnostics only): skip the epilogue
+  float* ws_part;    // split-K without atomics: partial tiles [split][tile][BM*BN] ...
+  int* ws_cnt;       // ... and per-tile arrival tickets (zero between launches); null = atomics
+  int ws_tiles;
 };
 
 // bijective XCD-aware remap: consecutive new ids share an XCD
@@ -517,10 +520,69 @@ void gemm_fast_kernel(const FastParams P) {
     return;
   }
   static_assert(NI == 2, "epilogue pieces are 64 columns wide");
+  bool atomic = nsplit > 1;
+  if constexpr (!K::SPEC) {
+    if (nsplit > 1 && P.ws_cnt) {
+      // Split-K through the workspace: dump this split's accumulators (raw register image, 1 KiB
+      // per wave-instruction), take a ticket for the tile; the last split to arrive adds the
+      // others' dumps to its registers and goes on to the ordinary epilogue.
+      // Coherence without fences: an agent-scope __threadfence() writes back / invalidates a whole
+      // XCD L2 on this part (measured: +100 us per launch).  Instead the dumps themselves are
+      // agent-coherent accesses (sc1 stores write through, sc1 loads re-validate), ordered against
+      // the ticket atomic by vmcnt(0) + the workgroup barrier.
+      const int tile_id = ((int)bz * P.tiles_m + tm) * P.tiles_n + tn;
+      constexpr int WAVE_ELEMS = MI * NI * 16 * 64;
+      float* mine = P.ws_part + ((int64_t)blockIdx.y * P.ws_tiles + tile_id) * (BM * BN) + wave * WAVE_ELEMS;
+#pragma unroll
+      for (int p = 0; p < MI; ++p)
+#pragma unroll
+        for (int q = 0; q < NI; ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = f32x4{acc[p][q][4 * g], acc[p][q][4 * g + 1], acc[p][q][4 * g + 2], acc[p][q][4 * g + 3]};
+            float* dst = mine + (((p * NI + q) * 4 + g) * 64 + lane) * 4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* ticket = reinterpret_cast<int*>(smem);
+      if (threadIdx.x == 0) *ticket = atomicAdd(P.ws_cnt + tile_id, 1);
+      __syncthreads();
+      const int tk = *reinterpret_cast<volatile int*>(ticket);
+      if (tk != nsplit - 1) return;
+      __syncthreads();  // everyone has read the ticket before the epilogue reuses that LDS
+      for (int sp = 0; sp < nsplit; ++sp) {
+        if (sp == (int)blockIdx.y) continue;
+        const float* src = P.ws_part + ((int64_t)sp * P.ws_tiles + tile_id) * (BM * BN) + wave * WAVE_ELEMS;
+#pragma unroll
+        for (int p = 0; p < MI; ++p) {
+          f32x4 t[NI * 4];
+#pragma unroll
+          for (int i = 0; i < NI * 4; ++i) {
+            const float* sp_ = src + ((p * NI * 4 + i) * 64 + lane) * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i]) : "v"(sp_) : "memory");
+          }
+          static_assert(NI == 2, "eight loads per wait below");
+          asm volatile("s_waitcnt vmcnt(0)"
+                       : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
+                       :
+                       : "memory");
+#pragma unroll
+          for (int q = 0; q < NI; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[p][q][4 * g + i] += t[q * 4 + g][i];
+        }
+      }
+      if (threadIdx.x == 0) P.ws_cnt[tile_id] = 0;  // ready for the next launch
+      atomic = false;
+    }
+  }
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int p = 0; p < MI; ++p)
-    wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, nsplit > 1);
+    wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, atomic);
 }
 
 // =====================================================================================
@@ -740,6 +802,9 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
+  P.ws_part = nullptr;
+  P.ws_cnt = nullptr;
+  P.ws_tiles = 0;
   auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && (CFG < 2 || CFG == 4 || CFG == 6)) {  // ablation builds exist for the bf16-out KC-A kernels only
     if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
@@ -793,12 +858,32 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     const int64_t slots = (CFG == 1 || CFG == 3 || CFG == 5 || CFG == 8) ? 256 : 512;
     const int64_t out_bytes = d.M * d.N * d.nbatch * 4;
     int64_t want = slots / wgs;
-    if (want > 5) want = 5;
     if (want > its / 4) want = its / 4;
-    const int64_t budget = its * 160 * 1024 + 3 * 1048576;
-    if (want > budget / out_bytes) want = budget / out_bytes;
+    // with a workspace the reduction is plain stores + one gather by the last split (cheap); the
+    // fp32-atomic fallback pays ~2 us per MB per split, so it is bounded by what the K loop amortises
+    const int64_t tiles_all = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
+    const int64_t cnt_bytes = (tiles_all * 4 + 4095) / 4096 * 4096;
+    static const int no_ws = [] { const char* e = getenv("TMI_GEMM_NO_WS"); return e ? atoi(e) : 0; }();
+    static const int ws_cap = [] { const char* e = getenv("TMI_GEMM_WS_MAXSPLIT"); return e ? atoi(e) : 8; }();
+    bool use_ws = !no_ws && !K::SPEC && d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0;
+    if (use_ws) {
+      if (want > ws_cap) want = ws_cap;
+      while (want > 1 && cnt_bytes + want * tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) --want;
+      if (cnt_bytes + tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) use_ws = false;
+    }
+    if (!use_ws) {
+      if (want > 5) want = 5;
+      const int64_t budget = its * 160 * 1024 + 3 * 1048576;
+      if (want > budget / out_bytes) want = budget / out_bytes;
+    }
     static const int force_split = [] { const char* e = getenv("TMI_GEMM_SPLIT"); return e ? atoi(e) : 0; }();
     if (force_split > 0) want = force_split < its ? force_split : its;
+    if (use_ws && cnt_bytes + want * tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) use_ws = false;
+    if (use_ws && want > 1) {
+      P.ws_cnt = reinterpret_cast<int*>(d.workspace);
+      P.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + cnt_bytes);
+      P.ws_tiles = (int)tiles_all;
+    }
     splitk = want < 1 ? 1 : (int)want;
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
@@ -828,6 +913,9 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   P.dbg = 0;
+  P.ws_part = nullptr;
+  P.ws_cnt = nullptr;
+  P.ws_tiles = 0;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, B_KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
   if (attr != hipSuccess) {

@@ -46,6 +46,20 @@ class GemmProfile:
 PROFILE = None  # set to a GemmProfile() to instrument
 
 
+_WORKSPACE = {}
+GEMM_WORKSPACE_BYTES = 96 << 20  # TMI_GEMM_WORKSPACE_MIN
+
+
+def gemm_workspace(device):
+    """Split-K scratch of tmi_gemm (partial tiles + per-tile tickets): zeroed once, one per device;
+    calls that use it must be ordered on one stream."""
+    key = (device.type, device.index)
+    ws = _WORKSPACE.get(key)
+    if ws is None:
+        ws = _WORKSPACE[key] = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
          kbatch=1, a_skb=0, b_skb=0, bias=None, bias_sb=0, scale_cols=0, scale=1.0, accumulate=False,
          act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
@@ -71,6 +85,9 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     d.resid = ptr(resid)
     d.r_ld, d.r_sb = r_ld, r_sb
     d.splitk = splitk
+    if splitk == 0 and Cm.is_cuda:
+        ws = gemm_workspace(Cm.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     assert A.dtype == B.dtype
     d.in_dtype, d.out_dtype = dt(A), dt(Cm)
     if PROFILE is None:

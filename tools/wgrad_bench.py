@@ -27,7 +27,11 @@ for T in (12000, 800):
         dW = torch.zeros(Kin, N, device=dev, dtype=torch.float32)
         fl = 2.0 * T * Kin * N
         row = []
+        ref = X.float().t() @ dY.float()
         for sk in splits:
+            dW.zero_()
+            ops.gemm(X, dY, dW, Kin, N, T, 1, Kin, N, 1, N, splitk=sk)
+            err = ((dW - ref).abs().max() / ref.abs().max()).item()
             us = t(lambda: ops.gemm(X, dY, dW, Kin, N, T, 1, Kin, N, 1, N, splitk=sk))
-            row.append(f"s{sk}:{us:6.1f}")
+            row.append(f"s{sk}:{us:6.1f}" + ("" if err < 1e-4 else f" ERR {err:.1e}"))
         print(f"T={T:5d} dW[{Kin:4d},{N:4d}] {fl * 1e-9:5.1f} GF  " + " ".join(row), flush=True)
