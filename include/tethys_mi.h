@@ -60,11 +60,11 @@ const char* tmi_last_error(void);
  * fp32 atomics into a PRE-ZEROED fp32 C (no epilogue terms allowed); splitk == 0 lets the
  * library choose (it only splits epilogue-free fp32-output GEMMs, i.e. weight gradients, and
  * then C must be pre-zeroed); splitk == 1 never splits.
- * workspace (optional, device memory, ZEROED ONCE by the caller and then owned by the library
- * between calls on one stream; TMI_GEMM_WORKSPACE_MIN bytes always suffice): when given, a
- * library-chosen split (splitk == 0) is reduced WITHOUT atomics — every split stores its partial
- * tile there and the last split to finish a tile (a per-tile ticket) sums them and runs the normal
- * epilogue, so C needs no zeroing and fp32 atomics (~0.5 TB/s on MI355X) leave the path.
+ * workspace (optional scratch in device memory, contents irrelevant, owned by the call while it
+ * runs on its stream; TMI_GEMM_WORKSPACE_MIN bytes always suffice): when given, a library-chosen
+ * split (splitk == 0) of a long reduction is reduced WITHOUT atomics — every split runs the epilogue
+ * into its own fp32 slab there and a streaming pass sums the slabs into C, so C needs no zeroing
+ * and fp32 atomics (~0.5 TB/s on MI355X) leave the path.
  * in_dtype: type of A and B; out_dtype: type of C, aux_*, resid.  Valid pairs:
  * (F32,F32), (BF16,BF16), (BF16,F32).  fp32 inputs use the exact-fp32 MFMA
  * (v_mfma_f32_32x32x2_f32); bf16 inputs use v_mfma_f32_32x32x16_bf16.

@@ -53,9 +53,7 @@ struct FastParams {
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
   int dbg;           // TMI_GEMM_DBG bit 1 (diagnostics only): skip the epilogue
-  float* ws_part;    // split-K without atomics: partial tiles [split][tile][BM*BN] ...
-  int* ws_cnt;       // ... and per-tile arrival tickets (zero between launches); null = atomics
-  int ws_tiles;
+  int64_t split_c_stride;  // != 0: split s stores (no atomics) to C + s * split_c_stride (workspace slabs)
 };
 
 // bijective XCD-aware remap: consecutive new ids share an XCD
@@ -229,8 +227,8 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
       *reinterpret_cast<float*>(E + epi_off(row, 32 + c)) = a1[reg];
     }
   }
-  TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
-  if (atomic) {  // split-K: fp32 atomics, 256 contiguous bytes per wave-instruction
+  TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb + (int64_t)blockIdx.y * P.split_c_stride;
+  if (atomic && P.split_c_stride == 0) {  // split-K: fp32 atomics, 256 contiguous bytes per wave-instruction
     if constexpr (sizeof(TC) == 4) {
       const int64_t n = nw + lane;
       if (n < d.N) {
@@ -350,6 +348,46 @@ template <> struct Cfg<7> { static constexpr int BM = 128, BN = 128, WM = 32, WN
 template <> struct Cfg<8> { static constexpr int BM = 256, BN = 256, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
 template <> struct Cfg<9> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
 template <int CFG> constexpr bool kRegStage = CFG >= 7;
+
+// Split-K through the workspace: every split runs the ordinary (non-atomic) epilogue into its own
+// fp32 slab [nbatch][M][N] of the caller's workspace, and splitk_reduce_kernel, launched right
+// behind on the same stream, sums the slabs into C.  Both passes are plain 16-byte streams at HBM
+// rate; fp32 atomics reach ~0.5 TB/s on this part, and an in-kernel "last split gathers" scheme
+// needs agent-scope coherence (whole-L2 write-backs) or sc1 accesses in a latency chain and pushed
+// the 256x256 kernels into register spills.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, int64_t slab_elems,
+                                                            float* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
+                                                            int64_t c_sb, int64_t nbatch, int accumulate, int vec_ok) {
+  const int64_t per_batch = M * N;
+  if (vec_ok) {  // N % 4 == 0, ldc % 4 == 0, 16-byte aligned bases
+    const int64_t nv = nbatch * per_batch / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+      const int64_t e = i * 4, b = e / per_batch, r = e - b * per_batch, m = r / N, n = r - m * N;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + e);
+      for (int sp = 1; sp < nsplit; ++sp) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + sp * slab_elems + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+      }
+      float* dst = C + b * c_sb + m * ldc + n;
+      if (accumulate) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += o[j];
+      }
+      *reinterpret_cast<f32x4*>(dst) = acc;
+    }
+  } else {
+    const int64_t ne = nbatch * per_batch;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < ne; e += (int64_t)gridDim.x * 256) {
+      const int64_t b = e / per_batch, r = e - b * per_batch, m = r / N, n = r - m * N;
+      float acc = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) acc += slabs[sp * slab_elems + e];
+      float* dst = C + b * c_sb + m * ldc + n;
+      *dst = accumulate ? *dst + acc : acc;
+    }
+  }
+}
 
 // ABL (diagnostics, compile-time so the production loop is untouched): 2 = no MFMA/fragment reads,
 // 4 = no staging after the prologue
@@ -520,65 +558,7 @@ void gemm_fast_kernel(const FastParams P) {
     return;
   }
   static_assert(NI == 2, "epilogue pieces are 64 columns wide");
-  bool atomic = nsplit > 1;
-  if constexpr (!K::SPEC) {
-    if (nsplit > 1 && P.ws_cnt) {
-      // Split-K through the workspace: dump this split's accumulators (raw register image, 1 KiB
-      // per wave-instruction), take a ticket for the tile; the last split to arrive adds the
-      // others' dumps to its registers and goes on to the ordinary epilogue.
-      // Coherence without fences: an agent-scope __threadfence() writes back / invalidates a whole
-      // XCD L2 on this part (measured: +100 us per launch).  Instead the dumps themselves are
-      // agent-coherent accesses (sc1 stores write through, sc1 loads re-validate), ordered against
-      // the ticket atomic by vmcnt(0) + the workgroup barrier.
-      const int tile_id = ((int)bz * P.tiles_m + tm) * P.tiles_n + tn;
-      constexpr int WAVE_ELEMS = MI * NI * 16 * 64;
-      float* mine = P.ws_part + ((int64_t)blockIdx.y * P.ws_tiles + tile_id) * (BM * BN) + wave * WAVE_ELEMS;
-#pragma unroll
-      for (int p = 0; p < MI; ++p)
-#pragma unroll
-        for (int q = 0; q < NI; ++q)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = f32x4{acc[p][q][4 * g], acc[p][q][4 * g + 1], acc[p][q][4 * g + 2], acc[p][q][4 * g + 3]};
-            float* dst = mine + (((p * NI + q) * 4 + g) * 64 + lane) * 4;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-          }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      int* ticket = reinterpret_cast<int*>(smem);
-      if (threadIdx.x == 0) *ticket = atomicAdd(P.ws_cnt + tile_id, 1);
-      __syncthreads();
-      const int tk = *reinterpret_cast<volatile int*>(ticket);
-      if (tk != nsplit - 1) return;
-      __syncthreads();  // everyone has read the ticket before the epilogue reuses that LDS
-      for (int sp = 0; sp < nsplit; ++sp) {
-        if (sp == (int)blockIdx.y) continue;
-        const float* src = P.ws_part + ((int64_t)sp * P.ws_tiles + tile_id) * (BM * BN) + wave * WAVE_ELEMS;
-#pragma unroll
-        for (int p = 0; p < MI; ++p) {
-          f32x4 t[NI * 4];
-#pragma unroll
-          for (int i = 0; i < NI * 4; ++i) {
-            const float* sp_ = src + ((p * NI * 4 + i) * 64 + lane) * 4;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[i]) : "v"(sp_) : "memory");
-          }
-          static_assert(NI == 2, "eight loads per wait below");
-          asm volatile("s_waitcnt vmcnt(0)"
-                       : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7])
-                       :
-                       : "memory");
-#pragma unroll
-          for (int q = 0; q < NI; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[p][q][4 * g + i] += t[q * 4 + g][i];
-        }
-      }
-      if (threadIdx.x == 0) P.ws_cnt[tile_id] = 0;  // ready for the next launch
-      atomic = false;
-    }
-  }
+  const bool atomic = nsplit > 1;
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int p = 0; p < MI; ++p)
@@ -633,9 +613,9 @@ __device__ __forceinline__ void p8_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename TC, bool B_KS>
+template <typename TC, bool A_KS, bool B_KS>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][128 rows][128 B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB]
   const tmi_gemm_desc& d = P.d;
   const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
   const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
@@ -646,47 +626,74 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-  const int nt = P.ktiles;
+  // this split's K-tiles [kt0, kt0 + nt)
+  const int nsplit = gridDim.y;
+  const int per = (P.ktiles + nsplit - 1) / nsplit;
+  const int kt0 = blockIdx.y * per;
+  const int nt = min(P.ktiles, kt0 + per) - kt0;  // may be <= 0 for a trailing split
+  // K tail (both operands k-strided, K % 8 == 0; host-checked): rows k >= klast of the last K-tile are
+  // fetched from row klast - 1 (in bounds) and the A fragments covering them are zeroed
+  const int klast = (int)(d.K - (int64_t)(P.ktiles - 1) * 64);
+  const bool tail = klast < 64;
   const char* Abase = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.A) + bz * d.a_sb);
   const char* Bbase = reinterpret_cast<const char*>(reinterpret_cast<const bf16_t*>(d.B) + bz * d.b_sb);
 
-  // ---- loop-invariant lane offsets of the staging loads: half-tile kind x wave-instruction
+  // ---- loop-invariant lane offsets of the staging loads: half-tile kind x wave-instruction.
+  // k-contiguous operand: half-tile = [128 rows][64 k] (128 B rows, chunk ^= (row >> 1) & 7); A^a holds
+  //   tile rows 128*w + 64*a + (0..63) at image rows 64*w + .., B^b tile columns 64*w + 32*b + (0..31)
+  //   at image rows 32*w + ...
+  // k-strided operand: half-tile = [64 k][128 cols] (256 B rows, stage_ks's swizzle), the same
+  //   row/column groups laid along the image columns.
   unsigned offA[2][2], offB[2][2];
+  int krs[2];  // k-row of this lane's two loads (k-strided images)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ir = 8 * (2 * wave + i) + (lane >> 3);  // image row
+    const int ir = 8 * (2 * wave + i) + (lane >> 3);  // image row (k-contiguous images)
     const int c = (lane & 7) ^ ((ir >> 1) & 7);
+    const int kr = 4 * (2 * wave + i) + (lane >> 4);  // image row (k-strided images)
+    const int cl = (lane & 15) ^ ((kr & 3) << 2);     // logical 8-column chunk this lane fetches
+    krs[i] = kr;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      int64_t gr = m0 + (ir >> 6) * 128 + 64 * a + (ir & 63);
-      gr = gr < d.M ? gr : d.M - 1;
-      offA[a][i] = (unsigned)((gr * d.a_sm + c * 8) * 2);
+      if constexpr (!A_KS) {
+        int64_t gr = m0 + (ir >> 6) * 128 + 64 * a + (ir & 63);
+        gr = gr < d.M ? gr : d.M - 1;
+        offA[a][i] = (unsigned)((gr * d.a_sm + c * 8) * 2);
+      } else {
+        int64_t gm = m0 + ((8 * cl) >> 6) * 128 + 64 * a + ((8 * cl) & 63);
+        gm = gm + 8 <= P.a_cols_rd ? gm : P.a_cols_rd - 8;
+        offA[a][i] = (unsigned)((kr * d.a_sk + gm) * 2);
+      }
       if constexpr (!B_KS) {
         int64_t gc = n0 + (ir >> 5) * 64 + 32 * a + (ir & 31);
         gc = gc < d.N ? gc : d.N - 1;
         offB[a][i] = (unsigned)((gc * d.b_sn + c * 8) * 2);
       } else {
-        // k-strided B: the half-tile is a [64 k][128 cols] image (256 B rows, stage_ks's swizzle); image
-        // columns 32w..32w+31 are tile columns 64w + 32b + (0..31)
-        const int kr = 4 * (2 * wave + i) + (lane >> 4);
-        const int cl = (lane & 15) ^ ((kr & 3) << 2);  // logical 8-column chunk this lane fetches
         int64_t gc = n0 + ((8 * cl) >> 5) * 64 + 32 * a + ((8 * cl) & 31);
         gc = gc + 8 <= P.b_cols_rd ? gc : P.b_cols_rd - 8;
         offB[a][i] = (unsigned)((kr * d.b_sk + gc) * 2);
       }
     }
   }
-  auto stage = [&](int buf, int kind, int kt) {  // kind: 0 A^0, 1 A^1, 2 B^0, 3 B^1
-    kt = kt < nt ? kt : nt - 1;
-    const char* src = kind < 2 ? Abase + (int64_t)kt * 128 : Bbase + (int64_t)kt * (B_KS ? 128 * d.b_sk : 128);
+  auto stage = [&](int buf, int kind, int t) {  // kind: 0 A^0, 1 A^1, 2 B^0, 3 B^1; t: tile within the split
+    t = t < nt ? t : nt - 1;
+    const int kt = kt0 + t;
+    const char* src = kind < 2 ? Abase + (int64_t)kt * (A_KS ? 128 * d.a_sk : 128) : Bbase + (int64_t)kt * (B_KS ? 128 * d.b_sk : 128);
     char* dst = smem + buf * P8_BUF + kind * P8_HALF + (2 * wave) * 1024;
-    const unsigned o0 = kind == 0 ? offA[0][0] : kind == 1 ? offA[1][0] : kind == 2 ? offB[0][0] : offB[1][0];
-    const unsigned o1 = kind == 0 ? offA[0][1] : kind == 1 ? offA[1][1] : kind == 2 ? offB[0][1] : offB[1][1];
+    unsigned o0 = kind == 0 ? offA[0][0] : kind == 1 ? offA[1][0] : kind == 2 ? offB[0][0] : offB[1][0];
+    unsigned o1 = kind == 0 ? offA[0][1] : kind == 1 ? offA[1][1] : kind == 2 ? offB[0][1] : offB[1][1];
+    if constexpr (A_KS && B_KS) {
+      if (tail && kt == P.ktiles - 1) {  // keep the fetch inside the operand: clamp the k-row
+        const int64_t sk2 = 2 * (kind < 2 ? d.a_sk : d.b_sk);
+        if (krs[0] >= klast) o0 -= (unsigned)((krs[0] - (klast - 1)) * sk2);
+        if (krs[1] >= klast) o1 -= (unsigned)((krs[1] - (klast - 1)) * sk2);
+      }
+    }
     glds16_so(src, o0, dst);
     glds16_so(src, o1, dst + 1024);
   };
 
-  // ---- fragment addresses: lane part is shared by A and B (same swizzle)
+  // ---- fragment addresses (k-contiguous images): the lane part is shared by A and B (same swizzle)
   const int r = lane & 31, h = lane >> 5;
   int xo[4];
 #pragma unroll
@@ -702,12 +709,32 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   bf16x8 ar[2][4], b0[4], b1[4];
 
-  auto readA = [&](int bufoff, int a) {
-    const char* img = smem + bufoff + a * P8_HALF + arow;
+  auto readA = [&](int bufoff, int a, int t) {
+    if constexpr (A_KS) {
+      const char* img = smem + bufoff + a * P8_HALF;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = *reinterpret_cast<const bf16x8*>(img + mi * 4096 + xo[kk]);
+        for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = frag_ks<false>(img, 64 * wr + 32 * mi, kk, lane);
+      if constexpr (B_KS) {
+        if (tail && kt0 + t == P.ktiles - 1) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if (16 * kk + 8 * h >= klast) {
+#pragma unroll
+              for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ar[mi][kk][j] = (bf16_t)0.f;
+            }
+        }
+      }
+    } else {
+      const char* img = smem + bufoff + a * P8_HALF + arow;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = *reinterpret_cast<const bf16x8*>(img + mi * 4096 + xo[kk]);
+    }
   };
   auto readB = [&](int bufoff, int b, bf16x8 (&br)[4]) {
     if constexpr (B_KS) {
@@ -728,52 +755,54 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
 
-  // ---- prologue: tile 0 whole, the first-read half of tile 1
-  stage(0, 2, 0);
-  stage(0, 0, 0);
-  stage(0, 3, 0);
-  stage(0, 1, 0);
-  stage(1, 2, 1);
-  stage(1, 0, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  p8_barrier();
-  if (wr == 1) p8_barrier();  // this group runs one barrier behind
+  if (nt > 0) {  // (uniform over the workgroup)
+    // ---- prologue: tile 0 whole, the first-read half of tile 1
+    stage(0, 2, 0);
+    stage(0, 0, 0);
+    stage(0, 3, 0);
+    stage(0, 1, 0);
+    stage(1, 2, 1);
+    stage(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p8_barrier();
+    if (wr == 1) p8_barrier();  // this group runs one barrier behind
 
-  // one K-tile per iteration: phases 5..8 of the table are phases 1..4 with the buffers swapped
-  for (int t = 0; t < nt; ++t) {
-    const int own = t & 1, oth = own ^ 1;
-    const int ownoff = own * P8_BUF;
-    readB(ownoff, 0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    readA(ownoff, 0);
-    stage(oth, 3, t + 1);
-    p8_barrier();
-    P8_MMA(0, 0, b0);
-    p8_barrier();
+    // one K-tile per iteration: phases 5..8 of the table are phases 1..4 with the buffers swapped
+    for (int t = 0; t < nt; ++t) {
+      const int own = t & 1, oth = own ^ 1;
+      const int ownoff = own * P8_BUF;
+      readB(ownoff, 0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      readA(ownoff, 0, t);
+      stage(oth, 3, t + 1);
+      p8_barrier();
+      P8_MMA(0, 0, b0);
+      p8_barrier();
 
-    readB(ownoff, 1, b1);
-    stage(oth, 1, t + 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    p8_barrier();
-    P8_MMA(0, 1, b1);
-    p8_barrier();
+      readB(ownoff, 1, b1);
+      stage(oth, 1, t + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      p8_barrier();
+      P8_MMA(0, 1, b1);
+      p8_barrier();
 
-    readA(ownoff, 1);
-    stage(own, 2, t + 2);
-    p8_barrier();
-    P8_MMA(1, 1, b1);
-    p8_barrier();
+      readA(ownoff, 1, t);
+      stage(own, 2, t + 2);
+      p8_barrier();
+      P8_MMA(1, 1, b1);
+      p8_barrier();
 
-    stage(own, 0, t + 2);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    p8_barrier();
-    P8_MMA(1, 0, b0);
+      stage(own, 0, t + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      p8_barrier();
+      P8_MMA(1, 0, b0);
+      p8_barrier();
+    }
+    if (wr == 0) p8_barrier();  // rejoin the other group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages must land before LDS is reused
     p8_barrier();
   }
 #undef P8_MMA
-  if (wr == 0) p8_barrier();  // rejoin the other group
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages must land before LDS is reused
-  p8_barrier();
 
   char* E = smem + wave * 8192;
 #pragma unroll
@@ -783,6 +812,32 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int64_t rup8(int64_t x) { return (x + 7) / 8 * 8; }
+
+// split-K through workspace slabs: run `launch` on a copy of P whose C is the workspace, then reduce
+template <typename F>
+int launch_with_slabs(const FastParams& P, int splitk, hipStream_t stream, F&& launch) {
+  const tmi_gemm_desc& d = P.d;
+  FastParams Q = P;
+  Q.d.C = d.workspace;
+  Q.d.ldc = d.N;
+  Q.d.c_sb = d.M * d.N;
+  Q.d.accumulate = 0;
+  Q.split_c_stride = d.nbatch * d.M * d.N;
+  Q.wide = d.N % 4 == 0;
+  launch(Q);
+  int rc = tmi_check_launch("tmi_gemm(split-K)");
+  if (rc) return rc;
+  float* C = reinterpret_cast<float*>(d.C);
+  const int vec_ok = d.N % 4 == 0 && d.ldc % 4 == 0 && d.c_sb % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  const int64_t n = d.nbatch * d.M * d.N;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                     reinterpret_cast<const float*>(d.workspace), splitk, Q.split_c_stride, C, d.M, d.N, d.ldc, d.c_sb,
+                     d.nbatch, d.accumulate, vec_ok);
+  return tmi_check_launch("tmi_gemm(split-K reduce)");
+}
 
 template <typename TC, bool A_KS, bool B_KS, int CFG>
 int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
@@ -802,9 +857,8 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
-  P.ws_part = nullptr;
-  P.ws_cnt = nullptr;
-  P.ws_tiles = 0;
+  P.split_c_stride = 0;
+  bool ws_split = false;
   auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && (CFG < 2 || CFG == 4 || CFG == 6)) {  // ablation builds exist for the bf16-out KC-A kernels only
     if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
@@ -859,64 +913,64 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     const int64_t out_bytes = d.M * d.N * d.nbatch * 4;
     int64_t want = slots / wgs;
     if (want > its / 4) want = its / 4;
-    // with a workspace the reduction is plain stores + one gather by the last split (cheap); the
-    // fp32-atomic fallback pays ~2 us per MB per split, so it is bounded by what the K loop amortises
-    const int64_t tiles_all = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
-    const int64_t cnt_bytes = (tiles_all * 4 + 4095) / 4096 * 4096;
+    // with a workspace the reduction is plain stores + one streaming reduce pass; the fp32-atomic
+    // fallback pays ~2 us per MB per split, so it is bounded by what the K loop amortises
+    const int64_t slab_bytes = out_bytes;  // one fp32 [nbatch][M][N] slab per split
     static const int no_ws = [] { const char* e = getenv("TMI_GEMM_NO_WS"); return e ? atoi(e) : 0; }();
     static const int ws_cap = [] { const char* e = getenv("TMI_GEMM_WS_MAXSPLIT"); return e ? atoi(e) : 8; }();
-    bool use_ws = !no_ws && !K::SPEC && d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0;
+    // (measured, tools/wgrad_bench.py: slabs + reduce launch match or beat atomics for long reductions,
+    // lose to them below ~64 K-tiles where the extra launch shows)
+    bool use_ws = !no_ws && sizeof(TC) == 4 && its >= 64 && d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0 &&
+                  2 * slab_bytes <= d.workspace_bytes;
     if (use_ws) {
       if (want > ws_cap) want = ws_cap;
-      while (want > 1 && cnt_bytes + want * tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) --want;
-      if (cnt_bytes + tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) use_ws = false;
-    }
-    if (!use_ws) {
+      if (want > d.workspace_bytes / slab_bytes) want = d.workspace_bytes / slab_bytes;
+    } else {
       if (want > 5) want = 5;
       const int64_t budget = its * 160 * 1024 + 3 * 1048576;
       if (want > budget / out_bytes) want = budget / out_bytes;
     }
     static const int force_split = [] { const char* e = getenv("TMI_GEMM_SPLIT"); return e ? atoi(e) : 0; }();
     if (force_split > 0) want = force_split < its ? force_split : its;
-    if (use_ws && cnt_bytes + want * tiles_all * (int64_t)K::BM * K::BN * 4 > d.workspace_bytes) use_ws = false;
-    if (use_ws && want > 1) {
-      P.ws_cnt = reinterpret_cast<int*>(d.workspace);
-      P.ws_part = reinterpret_cast<float*>(reinterpret_cast<char*>(d.workspace) + cnt_bytes);
-      P.ws_tiles = (int)tiles_all;
-    }
+    if (use_ws && want * slab_bytes > d.workspace_bytes) use_ws = false;
+    if (use_ws && want > 1) ws_split = true;
     splitk = want < 1 ? 1 : (int)want;
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
+  if (ws_split) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+    hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, Q);
+  });
   hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm(fast)");
 }
 
-// eight-phase kernel: (KC, KC), one K batch, no split-K, operand spans addressable with 32-bit byte offsets
-inline bool p8_eligible(const tmi_gemm_desc& d, bool b_ks) {
-  const double a_span = ((double)(d.M - 1) * (double)d.a_sm + (double)d.K) * 2.0;
+// eight-phase kernel: one K batch, operand spans addressable with 32-bit byte offsets; a K tail only
+// when both operands are k-strided (then K % 8 == 0); split-K only through the workspace
+inline bool p8_eligible(const tmi_gemm_desc& d, bool a_ks, bool b_ks) {
+  const double a_span = a_ks ? ((double)(d.K - 1) * (double)d.a_sk + (double)d.M + 8.0) * 2.0
+                             : ((double)(d.M - 1) * (double)d.a_sm + (double)d.K) * 2.0;
   const double b_span = b_ks ? ((double)(d.K - 1) * (double)d.b_sk + (double)d.N + 8.0) * 2.0
                              : ((double)(d.N - 1) * (double)d.b_sn + (double)d.K) * 2.0;
-  return d.kbatch == 1 && d.splitk <= 1 && d.K % 64 == 0 && d.K >= 128 && d.a_sm >= 0 && d.b_sn >= 0 && a_span < 4.0e9 &&
-         b_span < 4.0e9;
+  const bool k_ok = d.K % 64 == 0 || (a_ks && b_ks && d.K % 8 == 0);
+  return d.kbatch == 1 && k_ok && d.K >= 128 && d.a_sm >= 0 && d.b_sn >= 0 && d.a_sk >= 0 && d.b_sk >= 0 &&
+         a_span < 4.0e9 && b_span < 4.0e9;
 }
 
-template <typename TC, bool B_KS>
+template <typename TC, bool A_KS, bool B_KS>
 int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   FastParams P;
   P.d = d;
   P.tiles_m = (int)((d.M + 255) / 256);
   P.tiles_n = (int)((d.N + 255) / 256);
-  P.ktiles = (int)(d.K / 64);
-  P.a_cols_rd = 0;
+  P.ktiles = (int)((d.K + 63) / 64);
+  P.a_cols_rd = rup8(d.M);
   P.b_cols_rd = rup8(d.N);
   const int vecC = 16 / (int)sizeof(TC);
   P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
   P.dbg = 0;
-  P.ws_part = nullptr;
-  P.ws_cnt = nullptr;
-  P.ws_tiles = 0;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, B_KS>),
+  P.split_c_stride = 0;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
   if (attr != hipSuccess) {
     tmi_set_error("tmi_gemm(p8): cannot raise the dynamic LDS limit");
@@ -943,8 +997,26 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   P.xm = 8 / xn;
   P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
   P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
-  dim3 grid((unsigned)(8 * P.ptm * P.ptn), 1, (unsigned)d.nbatch);
-  hipLaunchKernelGGL((gemm_p8_kernel<TC, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, P);
+  // split-K (library-chosen only, fp32 output, workspace slabs only): fill the 256 CUs, >= 6 K-tiles per split
+  int splitk = 1;
+  if constexpr (sizeof(TC) == 4) {
+    const int64_t slab_bytes = d.M * d.N * d.nbatch * 4;
+    if (d.splitk == 0 && d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0 && !d.bias && !d.act &&
+        !d.aux_out && !d.aux_in && !d.resid && d.scale_cols <= 0) {
+      const int64_t wgs = (int64_t)8 * P.ptm * P.ptn * d.nbatch;
+      static const int cap = [] { const char* e = getenv("TMI_GEMM_P8_MAXSPLIT"); return e ? atoi(e) : 8; }();
+      int64_t want = 256 / wgs;
+      if (want > P.ktiles / 6) want = P.ktiles / 6;
+      if (want > cap) want = cap;
+      if (want > d.workspace_bytes / slab_bytes) want = d.workspace_bytes / slab_bytes;
+      if (want > 1) splitk = (int)want;
+    }
+  }
+  dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
+  if (splitk > 1) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+    hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, Q);
+  });
+  hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, P);
   return tmi_check_launch("tmi_gemm(p8)");
 }
 
@@ -959,8 +1031,8 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   const double round_eff = (double)big_tiles / (double)(((big_tiles + 255) / 256) * 256);
   const bool wgrad_like = d.splitk == 0 && d.out_dtype == TMI_F32;
   bool big = d.out_dtype == TMI_BF16 && d.M >= 2048 && d.N >= 512 && (d.K * d.kbatch >= 1536 || round_eff >= 0.8);
-  if constexpr (!A_KS) {
-    if (force == 10 && p8_eligible(d, B_KS)) return launch_p8<TC, B_KS>(d, stream);
+  if constexpr (!A_KS || B_KS) {  // (k-strided A with k-contiguous B is not instantiated)
+    if (force == 10 && p8_eligible(d, A_KS, B_KS) && d.splitk <= 1) return launch_p8<TC, A_KS, B_KS>(d, stream);
   }
   // too few 128x128 tiles to occupy the chip (and not a split-K weight gradient): 64x64 tiles
   const int64_t mid_tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nbatch;
@@ -976,15 +1048,23 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
   if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
   if (small) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  // weight gradients with a large output and a long reduction: eight-phase kernel, split-K through
+  // workspace slabs (-13 % against the 128x128 kernel with atomics; smaller outputs lose)
+  if constexpr (A_KS && B_KS && sizeof(TC) == 4) {
+    static const int no_p8w = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
+    if (!no_p8w && force < 0 && wgrad_like && d.workspace && p8_eligible(d, true, true) && d.M * d.N >= 768 * 2304 &&
+        d.K >= 4096 && d.nbatch == 1 && 2 * d.M * d.N * 4 <= d.workspace_bytes)
+      return launch_p8<TC, true, true>(d, stream);
+  }
   // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py): +20 % on long reductions; with a
   // k-strided B and a short K its un-overlapped epilogue (one workgroup per CU) loses to the two
   // co-resident 128x128 workgroups, so those stay where they were.
   if constexpr (!A_KS) {
     static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
-    if (!no_p8 && force < 0 && !wgrad_like && p8_eligible(d, B_KS) && d.M >= 2048 && d.N >= 256 &&
+    if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256 &&
         (d.K >= 1536 || (!B_KS && light_epi)))
-      return launch_p8<TC, B_KS>(d, stream);
+      return launch_p8<TC, false, B_KS>(d, stream);
   }
   return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
 }
