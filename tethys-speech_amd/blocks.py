@@ -131,6 +131,36 @@ class Arena:
 
 
 class KernelBlocks:
+    # ---- weight-gradient stream ------------------------------------------------------------
+    # dW = xᵀ·dy and db = colsum(dy) feed nothing until the optimizer (or the all-reduce), so they run
+    # on a second HIP stream beside the dgrad chain: many kernels of the chain (decoder-sized GEMMs,
+    # the N = 768 dgrads on 144 of 256 CUs, LayerNorm) leave most of the chip idle.  Hazards are
+    # tracked per dy buffer: the side stream starts after an event recorded when dy is complete, and
+    # any main-stream kernel that overwrites a buffer a queued weight gradient still reads waits for
+    # that reader first (_guard_write).  x operands are saved forward activations, never rewritten
+    # during backward.
+    _side = None
+
+    def enable_wgrad_stream(self, on=True):
+        on = on and self.device.type == "cuda"
+        self._side = torch.cuda.Stream(device=self.device) if on else None
+        self._side_reads = {}
+        return self
+
+    def _guard_write(self, *tensors):
+        if self._side is None or not self._side_reads:
+            return
+        for t in tensors:
+            ev = self._side_reads.pop(t.data_ptr(), None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def _join_side(self):
+        """Main stream waits for everything queued on the weight-gradient stream."""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_reads.clear()
+
     def refresh_shadows(self):
         """Re-derive the bf16 mirror from the fp32 master (after loading weights; the optimizer
         step keeps it current by itself)."""
@@ -178,12 +208,27 @@ class KernelBlocks:
         N = self.arena.shapes[wname][-1]
         M = x2d.shape[0]
         dW = self.arena.grad(wname).view(K_in, N)
-        ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N,
-                 splitk=0)
         bname = wname.replace(".kernel", ".bias")
-        if bname in self.arena.offsets:
-            ops.bias_grad(dy2d, self.arena.grad(bname))
+
+        def weight_grads():
+            ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N,
+                     splitk=0)
+            if bname in self.arena.offsets:
+                ops.bias_grad(dy2d, self.arena.grad(bname))
+
+        if self._side is None:
+            weight_grads()
+        else:
+            ready = torch.cuda.Event()
+            ready.record()  # dy is complete on the main stream here
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                weight_grads()
+                done = torch.cuda.Event()
+                done.record(self._side)
+            self._side_reads[dy2d.data_ptr()] = done
         if dx2d is not None:
+            self._guard_write(dx2d)
             ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
                      accumulate=accumulate_dx, aux_in=aux_in)
 
@@ -194,6 +239,7 @@ class KernelBlocks:
 
     def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate):
         a = self.arena
+        self._guard_write(dx2d)
         ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
                           dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
 
@@ -224,6 +270,7 @@ class KernelBlocks:
         scaling = hd ** -0.5
         (qt, qo), (kt, ko), (vt, vo) = q, k, v
         (dqt, dqo), (dkt, dko), (dvt, dvo) = dq, dk, dv
+        self._guard_write(dqt, dkt, dvt)
         if self.precision == "bf16":
             def m(t, off, T):
                 return (t, off, T * t.stride(0), t.stride(0))

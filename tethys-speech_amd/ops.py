@@ -51,9 +51,9 @@ GEMM_WORKSPACE_BYTES = 96 << 20  # TMI_GEMM_WORKSPACE_MIN
 
 
 def gemm_workspace(device):
-    """Split-K scratch of tmi_gemm (partial tiles + per-tile tickets): zeroed once, one per device;
-    calls that use it must be ordered on one stream."""
-    key = (device.type, device.index)
+    """Split-K scratch of tmi_gemm (one fp32 slab per split): one per (device, stream), since calls
+    that share it must be ordered on one stream."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)  # one per stream in use
     ws = _WORKSPACE.get(key)
     if ws is None:
         ws = _WORKSPACE[key] = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)

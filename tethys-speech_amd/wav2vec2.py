@@ -18,6 +18,7 @@ positional Conv1D runs as one batched window-GEMM over a group-major repack.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -156,6 +157,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self.seg_vars = so.to(self.device)
         self.seg_all = torch.tensor([0, self.arena.numel], dtype=torch.int64, device=self.device)
         self.refresh_shadows()
+        # (opt-in here: at B*T = 800 rows the step gains nothing from the second stream, and the hard
+        # quantiser makes the bf16 loss curve sensitive to the order of the fp32 atomics it perturbs)
+        self.enable_wgrad_stream(os.environ.get("TMI_WGRAD_STREAM", "0") == "1")
 
     def refresh_shadows(self):
         super().refresh_shadows()
@@ -448,6 +452,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             # odd padded rows u = 2j + 1: tap kk = 1
             ops.gemm(dup, w, din, Ti, cin, c, c, 1, 1, ldw, 2 * cin, nbatch=B, a_sb=dup.stride(0), c_sb=din.stride(0),
                      a_off=c, b_off=cin * ldw, c_off=cin)
+        self._join_side()
         return ws["loss"]
 
     def __call__(self, inputs, neg_indices=None, training=True):

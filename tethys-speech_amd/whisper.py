@@ -17,6 +17,7 @@ be reproduced, so a step with dropout has no parity definition.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -182,6 +183,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
         if precision == "bf16":
             self.mirror = torch.zeros(self.arena.numel, dtype=torch.bfloat16, device=self.device)
             self.refresh_shadows()
+        # weight / bias gradients on a second stream beside the dgrad chain (blocks.KernelBlocks)
+        self.enable_wgrad_stream(os.environ.get("TMI_WGRAD_STREAM", "1") != "0")
 
     # -- weights ---------------------------------------------------------------------
 
@@ -312,6 +315,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             """Everything stored at or after parameter ``name`` now has its final gradient."""
             lo = a.offsets[name]
             if grad_ready is not None and lo < done[0]:
+                self._join_side()  # weight gradients queued on the side stream are part of the range
                 grad_ready(lo, done[0])
                 done[0] = lo
 
@@ -479,6 +483,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
                  b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=0)
         ready("encoder.conv1.kernel")
+        self._join_side()
         return ws["loss"]
 
     def __call__(self, features, labels=None, training=True):
