@@ -13,8 +13,9 @@ per-GPU batch is fixed, value = 30 s * 8 * N * K / max-over-ranks wall time.
 Also reported on the same JSON line:
   roofline      the dominant kernel class (the MFMA GEMM, tmi_gemm): algorithmic FLOPs of
                 every tmi_gemm launch in a step / their device time measured with HIP events
-                recorded on the launch stream during an instrumented pass of the same steps,
-                against the 2.5 PFLOP/s dense bf16 MFMA peak.
+                recorded on the launch stream during an instrumented pass of the same steps
+                (weight-gradient side stream off, so launches do not overlap), against the
+                2.5 PFLOP/s dense bf16 MFMA peak.
   cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the
                 host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up +
                 2 timed steps of the same model and clip length).
@@ -177,18 +178,33 @@ def main():
 
     roof = None
     if not args.no_roofline:
-        # instrumented pass: HIP events around every tmi_gemm launch, on the launch stream
+        # instrumented pass: HIP events around every tmi_gemm launch, on the launch stream.  The
+        # weight-gradient side stream is switched off for it, so each GEMM runs alone and its
+        # duration is its own (in the timed region above weight gradients overlap the dgrad chain).
+        overlap = model._side is not None
+        model.enable_wgrad_stream(False)
         ops.PROFILE = ops.GemmProfile()
         nprof = min(args.steps, 3)
         for _ in range(nprof):
             one_step()
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
+        model.enable_wgrad_stream(overlap)
         ms, flops, launches = prof.totals()
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_kernel (tmi_gemm: all Dense/Conv1D fwd, dgrad, wgrad GEMMs)",
+        # HBM traffic cannot be counted from inside the process: it comes from the last committed PMC
+        # passes over this same command (tools/pmc_traffic.py), bytes per tmi_gemm launch
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_gemm_pmc_traffic.json: " + pmc["source"]
+        except Exception:
+            pass
+        roof = {"bound": "mfma", "kernel": "tmi_gemm kernels (gemm_fast_kernel / gemm_p8_kernel / gemm_kernel: all Dense/Conv1D fwd, dgrad, wgrad GEMMs)",
                 "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                "traffic_source": traffic_src,
                 "launches_per_step": launches / nprof, "gemm_ms_per_step": ms / nprof,
                 "gemm_gflop_per_step": flops / nprof / 1e9,
                 "avg_launch_us": ms * 1e3 / max(1, launches)}
