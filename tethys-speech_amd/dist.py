@@ -92,8 +92,12 @@ class DataParallelStrategy:
         if (self._pend_hi - self._pend_lo) * 4 >= self.bucket_bytes:
             self._launch()
 
+    pre_launch = None  # optional hook: order the compute stream after side-stream gradient producers
+
     def _launch(self):
         if self._pend_hi > self._pend_lo:
+            if self.pre_launch is not None:
+                self.pre_launch()
             # RCCL orders this after everything already enqueued on the compute stream and runs it
             # on its own stream, under the rest of backward
             self._works.append(dist.all_reduce(self._g[self._pend_lo:self._pend_hi], op=dist.ReduceOp.SUM, async_op=True))

@@ -18,6 +18,7 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
     A replica whose slice of a short final batch is empty contributes zero gradients."""
     features, labels = dist_inputs
     strategy.begin_gradients(model.arena.g)
+    strategy.pre_launch = model._join_side  # weight gradients run on the model's second stream
     if features.shape[0] > 0:
         loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready)
     else:

@@ -315,7 +315,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
             """Everything stored at or after parameter ``name`` now has its final gradient."""
             lo = a.offsets[name]
             if grad_ready is not None and lo < done[0]:
-                self._join_side()  # weight gradients queued on the side stream are part of the range
+                # (a consumer that acts on the range at once must first order itself after the
+                # weight-gradient stream: DataParallelStrategy does so through its pre_launch hook)
                 grad_ready(lo, done[0])
                 done[0] = lo
 
