@@ -145,7 +145,34 @@ class KernelBlocks:
         on = on and self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if on else None
         self._side_reads = {}
+        # events are reused round-robin: creating two per launch costs more host time than the
+        # decoder-sized kernels take (re-recording an event other work already waited on is legal)
+        self._ev_ring = [torch.cuda.Event() for _ in range(128)] if on else []
+        self._ev_i = 0
         return self
+
+    def _event(self):
+        ev = self._ev_ring[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._ev_ring)
+        return ev
+
+    def _run_on_side(self, fn, dy):
+        """Launch ``fn``'s kernels (readers of the finished buffer ``dy``, writers of gradients only)
+        on the weight-gradient stream, or inline if there is none."""
+        if self._side is None:
+            fn()
+            return
+        ready = self._event()
+        ready.record()  # dy is complete on the main stream here
+        self._side.wait_event(ready)
+        ops.set_stream(self._side.cuda_stream)
+        try:
+            fn()
+        finally:
+            ops.set_stream(None)
+        done = self._event()
+        done.record(self._side)
+        self._side_reads[dy.data_ptr()] = done
 
     def _guard_write(self, *tensors):
         if self._side is None or not self._side_reads:
@@ -216,17 +243,7 @@ class KernelBlocks:
             if bname in self.arena.offsets:
                 ops.bias_grad(dy2d, self.arena.grad(bname))
 
-        if self._side is None:
-            weight_grads()
-        else:
-            ready = torch.cuda.Event()
-            ready.record()  # dy is complete on the main stream here
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ready)
-                weight_grads()
-                done = torch.cuda.Event()
-                done.record(self._side)
-            self._side_reads[dy2d.data_ptr()] = done
+        self._run_on_side(weight_grads, dy2d)
         if dx2d is not None:
             self._guard_write(dx2d)
             ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),

@@ -23,8 +23,18 @@ def dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+_STREAM_OVERRIDE: Optional[int] = None
+
+
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t every wrapper launches on: torch's current stream, unless a caller has pinned
+    another one with ``set_stream`` (cheaper than switching torch's current stream per launch)."""
+    return _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream().cuda_stream
+
+
+def set_stream(handle: Optional[int]):
+    global _STREAM_OVERRIDE
+    _STREAM_OVERRIDE = handle
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -53,10 +63,10 @@ GEMM_WORKSPACE_BYTES = 96 << 20  # TMI_GEMM_WORKSPACE_MIN
 def gemm_workspace(device):
     """Split-K scratch of tmi_gemm (one fp32 slab per split): one per (device, stream), since calls
     that share it must be ordered on one stream."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)  # one per stream in use
+    key = (device.type, device.index, stream())  # one per stream in use
     ws = _WORKSPACE.get(key)
     if ws is None:
-        ws = _WORKSPACE[key] = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        ws = _WORKSPACE[key] = torch.empty(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)  # contents irrelevant
     return ws
 
 
