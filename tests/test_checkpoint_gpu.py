@@ -1,0 +1,49 @@
+"""Checkpoint save + restore (save: W:916-919,956 — the reference has no restore):
+a restored (model, optimizer) continues on exactly the trajectory of the original."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_checkpoint_roundtrip_continues_training(dev, tmp_path):
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist, optim, train, whisper
+    kw = dict(d_model=128, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=256, vocab_size=160,
+              encoder_layers=1, decoder_layers=1, n_mels=16, n_ctx=32, decoder_start_token_id=150,
+              max_target_positions=32)
+    rng = np.random.default_rng(0)
+    batches = [(torch.from_numpy(rng.standard_normal((2, 16, 48)).astype(np.float32)).to(dev),
+                torch.from_numpy(rng.integers(0, 150, (2, 12)).astype(np.int32)).to(dev)) for _ in range(4)]
+    strat = dist.DataParallelStrategy(0, 1)
+
+    def run(model, opt, bs):
+        return [float(train.distributed_train_step(strat, model, b, opt).item()) for b in bs]
+
+    m1 = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=5, **kw)
+    o1 = optim.Adam(1e-3)
+    run(m1, o1, batches[:2])
+    path = str(tmp_path / "ck.pt")
+    train.save_checkpoint(m1, o1, path)
+    ref = run(m1, o1, batches[2:])
+
+    m2 = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=99, **kw)  # different init
+    o2 = optim.Adam(1e-3)
+    train.load_checkpoint(m2, o2, path)
+    assert o2.iterations == 2
+    got = run(m2, o2, batches[2:])
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-6), (got, ref)
+
+    # bf16 mode: the mirror is rebuilt from the restored master weights
+    m3 = whisper.create_whisper_model("small", device=dev, precision="bf16", seed=99, **kw)
+    o3 = optim.Adam(1e-3)
+    train.load_checkpoint(m3, o3, path)
+    w = m3.arena.p[:1024]
+    assert torch.equal(m3.mirror[:1024], w.to(torch.bfloat16))
+
+    # a checkpoint of another layout is refused
+    kw2 = dict(kw, d_ff=128)
+    m4 = whisper.create_whisper_model("small", device=dev, precision="fp32", **kw2)
+    with pytest.raises(ValueError):
+        train.load_checkpoint(m4, optim.Adam(1e-3), path)

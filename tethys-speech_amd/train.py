@@ -30,13 +30,25 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
 
 def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4, *, batch_size=1,
                   num_batches=40, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print, seed=1234,
-                  model_overrides=None, seq_len=3000, max_target_length=100):
-    """W:894-958: model + Adam(1e-4), dummy dataset, per-step log line, checkpoint at epoch end."""
+                  model_overrides=None, seq_len=3000, max_target_length=100, tensor_log_dir=None,
+                  resume_from=None):
+    """W:894-958: model + Adam(1e-4), dummy dataset, per-step log line, checkpoint at epoch end.
+    ``tensor_log_dir``: also write the tensor-size / skewness report of the reference's
+    ``whisper_dist_tensorsize.py`` there (computed from shapes, see tensorsize.py).
+    ``resume_from``: checkpoint to restore before training (the reference has no restore)."""
     model = create_whisper_model(model_type, device=device, precision=precision, seed=seed,
                                  **(model_overrides or {}))
     strategy.broadcast_parameters(model.arena.p)
     model.refresh_shadows()
     optimizer = Adam(learning_rate=learning_rate)
+    if resume_from:
+        load_checkpoint(model, optimizer, resume_from)
+    report = None
+    if tensor_log_dir and strategy.rank == 0:
+        from .tensorsize import TensorSizeReport
+        report = TensorSizeReport(model, batch_size, seq_len, max_target_length, log_dir=tensor_log_dir,
+                                  model_label=f"whisper_{model_type}")
+        report.log_parameters(0)
     ds = create_dummy_dataset(batch_size, n_mels=model.config.n_mels, seq_len=seq_len,
                               max_target_length=max_target_length, device=device, rank=strategy.rank,
                               world=strategy.world, seed=seed, drop_remainder=strategy.world > 1)
@@ -55,10 +67,16 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
             losses.append(lv)
             log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
                 f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
+            if report is not None:
+                report.log_step(step)
             step += 1
         if checkpoint_dir and strategy.rank == 0:
             os.makedirs(checkpoint_dir, exist_ok=True)
             save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"whisper_{model_type}_epoch_{epoch + 1}.pt"))
+    if report is not None:
+        summ = report.save_final_results()
+        report.close()
+        log(f"Tiresias tensorsize: {summ['tiresias_tensorsize_mb']:.2f} MB, skewness: {summ['model_skewness']:.3f}")
     model.losses = losses
     return model
 
@@ -74,7 +92,7 @@ def load_checkpoint(model, optimizer, path):
     """The restore path the reference lacks."""
     ck = torch.load(path, map_location="cpu")
     a = model.arena
-    if ck["names"] != a.names:
+    if ck["names"] != a.names or ck["offsets"] != a.offsets or ck["shapes"] != a.shapes or ck["p"].numel() != a.p.numel():
         raise ValueError("checkpoint layout does not match the model")
     a.p.copy_(ck["p"]); a.m.copy_(ck["m"]); a.v.copy_(ck["v"])
     optimizer.iterations = int(ck["iterations"])
@@ -143,6 +161,8 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             losses.append(lv)
             log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
                 f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
+            if report is not None:
+                report.log_step(step)
             step += 1
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
                 os.makedirs(checkpoint_dir, exist_ok=True)
