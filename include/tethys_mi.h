@@ -278,6 +278,18 @@ int tmi_segment_clip(float* g, const int64_t* seg_off, const float* sumsq, int64
  * NaN guard, / num_replicas) without a host round trip. */
 int tmi_loss_combine(const float* a, const float* b, float w, float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Log-mel front end (speech_jobs/whisper_dist.py:739-766, extract_fbank_features; dead in the
+ * reference's training path).  The windowed DFT of the frames is a tmi_gemm
+ * (frames = overlapping rows of the waveform, a_sm = hop; B = [n_fft, 2*n_bins] Hann-weighted
+ * cos | -sin); this entry turns spec[frames, ld_spec] = [re | im] into
+ * log(|X|^2 . mel[n_bins, n_mels] + eps), written frame-major out[f*ld_out + m] (the reference's
+ * layout, W:764) or channels-first out[m*ld_out + f] (what the encoder reads).  fp32.
+ */
+int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, const float* mel, float* out,
+                             int64_t frames, int32_t n_bins, int32_t n_mels, float eps,
+                             int32_t channels_first, int64_t ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ SIGNATURES = {
     "tmi_transpose_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_feat_to_channels_last": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_sumsq": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "tmi_logmel_from_spectrum": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_i64, c_vp]),
     "tmi_groupnorm_chunks": (c_i64, [c_i64]),
     "tmi_groupnorm_gelu_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_groupnorm_gelu_bwd": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
@@ -87,7 +88,7 @@ SIGNATURES = {
     "tmi_loss_combine": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

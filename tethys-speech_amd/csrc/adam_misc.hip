@@ -210,3 +210,50 @@ extern "C" int tmi_sumsq(const float* x, float* out, int64_t n, int32_t accumula
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, out, n);
   return tmi_check_launch("tmi_sumsq");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Log-mel epilogue of the audio front end (speech_jobs/whisper_dist.py:752-764): the windowed DFT is
+// a tmi_gemm (frames as overlapping rows, Hann folded into the cos | -sin matrix); this kernel turns
+// one frame's spectrum [re(0..nb-1) | im(0..nb-1)] into power, applies the mel matrix [nb, n_mels] and
+// writes log(mel + eps), either frame-major [F, n_mels] (the reference's layout) or channels-first
+// [n_mels, F] (what the encoder consumes).  One wave per frame; HBM-bound (2*nb*4 B in, n_mels*4 B out).
+namespace {
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ spec, int64_t lds_, const float* __restrict__ mel,
+                                                     float* __restrict__ out, int64_t F, int nb, int n_mels, float eps,
+                                                     int channels_first, int64_t out_ld) {
+  extern __shared__ float pw[];  // [4 waves][nb]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t f = (int64_t)blockIdx.x * 4 + wave;
+  if (f >= F) return;  // (whole wave; no block barrier below)
+  float* p = pw + wave * nb;
+  const float* s = spec + f * lds_;
+  for (int k = lane; k < nb; k += 64) {
+    const float re = s[k], im = s[nb + k];
+    p[k] = re * re + im * im;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's LDS writes are visible to its own reads
+  for (int m = lane; m < n_mels; m += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < nb; ++k) acc = fmaf(p[k], mel[(int64_t)k * n_mels + m], acc);
+    const float v = logf(acc + eps);
+    if (channels_first) out[(int64_t)m * out_ld + f] = v;
+    else out[f * out_ld + m] = v;
+  }
+}
+}  // namespace
+
+extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, const float* mel, float* out, int64_t frames,
+                                        int32_t n_bins, int32_t n_mels, float eps, int32_t channels_first, int64_t ld_out,
+                                        void* stream) {
+  if (!spec || !mel || !out || frames <= 0 || n_bins <= 0 || n_mels <= 0 || ld_spec < 2 * (int64_t)n_bins ||
+      ld_out < (channels_first ? frames : (int64_t)n_mels) || n_bins > 4096) {
+    tmi_set_error("tmi_logmel_from_spectrum: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  const int64_t blocks = (frames + 3) / 4;
+  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)blocks), dim3(256), (size_t)4 * n_bins * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), spec, ld_spec, mel, out, frames, (int)n_bins, (int)n_mels, eps,
+                     (int)channels_first, ld_out);
+  return tmi_check_launch("tmi_logmel_from_spectrum");
+}
