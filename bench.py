@@ -166,9 +166,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
+    t_host = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside a step)
     torch.cuda.synchronize()
     strategy.barrier()
     dt = time.perf_counter() - t0
+    log(f"host enqueue {t_host / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step wall")
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)

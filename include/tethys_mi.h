@@ -192,6 +192,16 @@ int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stre
 int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
                   float weight_decay, float gscale, void* bf16_mirror, void* stream);
+/* The step-dependent scalars of tmi_adam_step, computed on the host exactly as it does:
+ * out3 = {step_size, vcorr_inv_sqrt, 1 - lr*weight_decay}. */
+int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode,
+                     float weight_decay, float* out3);
+/* tmi_adam_step with those three scalars read from DEVICE memory (dev_scalars[3]): nothing in the
+ * launch changes from step to step, so it can be part of a captured HIP graph. */
+int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1,
+                      float beta2, float eps, const float* dev_scalars, int32_t eps_mode,
+                      float gscale, void* bf16_mirror, void* stream);
+
 
 /* bf16 shadows of fp32 master weights: dst[r*ldd + c] = bf16(src[r*lds + c]) and the
  * transposed form dst[c*ldd + r] = bf16(src[r*lds + c]); pad columns [cols, ldd) of the

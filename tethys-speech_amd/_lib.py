@@ -69,6 +69,8 @@ SIGNATURES = {
     "tmi_xent_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_sum_scale": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    "tmi_adam_scalars": (c_i32, [c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp]),
+    "tmi_adam_step_dev": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_i32, c_f32, c_vp, c_vp]),
     "tmi_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_transpose_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
     "tmi_feat_to_channels_last": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
@@ -88,7 +90,7 @@ SIGNATURES = {
     "tmi_loss_combine": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -43,8 +43,15 @@ class Arena:
         self.names = [n for n, _ in spec]
 
     def view(self, buf: torch.Tensor, name: str) -> torch.Tensor:
-        o, s = self.offsets[name], self.shapes[name]
-        return buf[o:o + int(np.prod(s))].view(*s)
+        # views are cached per (buffer, name): the step asks for ~400 of them and building one costs
+        # more host time than launching a decoder-sized kernel
+        cache = self.__dict__.setdefault("_views", {})
+        key = (buf.data_ptr(), buf.dtype, name)
+        t = cache.get(key)
+        if t is None:
+            o, s = self.offsets[name], self.shapes[name]
+            t = cache[key] = buf[o:o + int(np.prod(s))].view(*s)
+        return t
 
     def param(self, name):
         return self.view(self.p, name)
@@ -140,10 +147,24 @@ class KernelBlocks:
     # that reader first (_guard_write).  x operands are saved forward activations, never rewritten
     # during backward.
     _side = None
+    _main = None  # the stream a step runs on, pinned for its duration (begin_step / end_step)
+
+    def begin_step(self):
+        """Pin the launch stream for one forward+backward: looking torch's current stream up costs
+        ~1 us per launch (2800 lookups per step)."""
+        if self.device.type == "cuda":
+            self._main = torch.cuda.current_stream(self.device)
+            self._prev_override = ops.set_stream(self._main.cuda_stream)
+
+    def end_step(self):
+        if self._main is not None:
+            ops.set_stream(self._prev_override)
+            self._main = None
 
     def enable_wgrad_stream(self, on=True):
         on = on and self.device.type == "cuda"
         self._side = torch.cuda.Stream(device=self.device) if on else None
+        self._side_handle = self._side.cuda_stream if on else None
         self._side_reads = {}
         # events are reused round-robin: creating two per launch costs more host time than the
         # decoder-sized kernels take (re-recording an event other work already waited on is legal)
@@ -163,13 +184,13 @@ class KernelBlocks:
             fn()
             return
         ready = self._event()
-        ready.record()  # dy is complete on the main stream here
+        ready.record(self._main or torch.cuda.current_stream())  # dy is complete on the main stream here
         self._side.wait_event(ready)
-        ops.set_stream(self._side.cuda_stream)
+        prev = ops.set_stream(self._side_handle)
         try:
             fn()
         finally:
-            ops.set_stream(None)
+            ops.set_stream(prev)
         done = self._event()
         done.record(self._side)
         self._side_reads[dy.data_ptr()] = done
@@ -180,7 +201,7 @@ class KernelBlocks:
         for t in tensors:
             ev = self._side_reads.pop(t.data_ptr(), None)
             if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+                (self._main or torch.cuda.current_stream()).wait_event(ev)
 
     def _join_side(self):
         """Main stream waits for everything queued on the weight-gradient stream."""
@@ -198,10 +219,15 @@ class KernelBlocks:
 
     def W(self, name) -> Tuple[torch.Tensor, int]:
         """(2-D weight tensor [in, out], leading dimension) in the compute dtype."""
-        shape = self.arena.shapes[name]
-        rows = int(np.prod(shape[:-1]))
         buf = self.mirror if self.precision == "bf16" else self.arena.p
-        return self.arena.view(buf, name).view(rows, shape[-1]), shape[-1]
+        cache = self.__dict__.setdefault("_w2d", {})
+        key = (buf.data_ptr(), name)
+        hit = cache.get(key)
+        if hit is None:
+            shape = self.arena.shapes[name]
+            rows = int(np.prod(shape[:-1]))
+            hit = cache[key] = (self.arena.view(buf, name).view(rows, shape[-1]), shape[-1])
+        return hit
 
     def _gemm_xw(self, A, wname, Cm, M, N, K, a_sm, *, n_off=0, **kw):
         """Cm = A · W[:, n_off:n_off+N] with W the natural [K, N_total] kernel (forward)."""

@@ -25,7 +25,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float b1,
                                                    float b2, float eps, float step_size, float vcorr_inv_sqrt,
                                                    int eps_mode, float decay, float gscale,
-                                                   bf16_t* __restrict__ mirror) {
+                                                   bf16_t* __restrict__ mirror, const float* __restrict__ dev_scalars) {
+  if (dev_scalars) {  // step-dependent scalars from device memory (a captured graph replays this launch)
+    step_size = dev_scalars[0];
+    vcorr_inv_sqrt = dev_scalars[1];
+    decay = dev_scalars[2];
+  }
   const int64_t nvec = n / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
@@ -144,8 +149,47 @@ extern "C" int tmi_adam_step(float* p, const float* g, float* m, float* v, int64
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
                      m, v, n, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale,
-                     (bf16_t*)bf16_mirror);
+                     (bf16_t*)bf16_mirror, (const float*)nullptr);
   return tmi_check_launch("tmi_adam_step");
+}
+
+// host-side scalars of one Adam step, exactly as tmi_adam_step derives them: out3 = {step_size, vcorr_inv_sqrt, decay}
+extern "C" int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode, float weight_decay,
+                                float* out3) {
+  if (!out3 || step <= 0 || (eps_mode != 0 && eps_mode != 1)) {
+    tmi_set_error("tmi_adam_scalars: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  const double c1 = 1.0 - pow((double)beta1, (double)step);
+  const double c2 = 1.0 - pow((double)beta2, (double)step);
+  if (eps_mode == 0) {
+    out3[0] = (float)((double)lr * sqrt(c2) / c1);
+    out3[1] = 1.0f;
+  } else {
+    out3[0] = (float)((double)lr / c1);
+    out3[1] = (float)(1.0 / sqrt(c2));
+  }
+  out3[2] = 1.0f - lr * weight_decay;
+  return TMI_OK;
+}
+
+// the same update with the step-dependent scalars read from DEVICE memory (dev_scalars[3], filled from
+// tmi_adam_scalars before each replay): the launch itself carries nothing that changes from step to
+// step, so it can sit in a captured HIP graph
+extern "C" int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                                 float eps, const float* dev_scalars, int32_t eps_mode, float gscale, void* bf16_mirror,
+                                 void* stream) {
+  if (!p || !g || !m || !v || !dev_scalars || n <= 0 || (eps_mode != 0 && eps_mode != 1) || !al16(p) || !al16(g) ||
+      !al16(m) || !al16(v) || (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7))) {
+    tmi_set_error("tmi_adam_step_dev: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
+                     m, v, n, beta1, beta2, eps, 0.f, 1.f, eps_mode, 1.f, gscale, (bf16_t*)bf16_mirror, dev_scalars);
+  return tmi_check_launch("tmi_adam_step_dev");
 }
 
 extern "C" int tmi_cast_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols,

@@ -32,9 +32,11 @@ def stream() -> int:
     return _STREAM_OVERRIDE if _STREAM_OVERRIDE is not None else torch.cuda.current_stream().cuda_stream
 
 
-def set_stream(handle: Optional[int]):
+def set_stream(handle: Optional[int]) -> Optional[int]:
+    """Pin (or, with None, unpin) the launch stream; returns the previous pin so callers can nest."""
     global _STREAM_OVERRIDE
-    _STREAM_OVERRIDE = handle
+    prev, _STREAM_OVERRIDE = _STREAM_OVERRIDE, handle
+    return prev
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -210,6 +212,18 @@ def sum_scale(x, out, n, scale):
 def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0, mirror=None):
     check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
                               eps, step, eps_mode, weight_decay, gscale, ptr(mirror), stream()), "tmi_adam_step")
+
+
+def adam_scalars(lr, beta1, beta2, step, eps_mode=0, weight_decay=0.0):
+    """[step_size, vcorr_inv_sqrt, decay] of one Adam step (host floats, as tmi_adam_step derives them)."""
+    out = (C.c_float * 3)()
+    check(lib().tmi_adam_scalars(lr, beta1, beta2, step, eps_mode, weight_decay, C.cast(out, C.c_void_p)), "tmi_adam_scalars")
+    return [out[0], out[1], out[2]]
+
+
+def adam_step_dev(p, g, m, v, n, beta1, beta2, eps, dev_scalars, eps_mode=0, gscale=1.0, mirror=None):
+    check(lib().tmi_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, beta1, beta2, eps,
+                                  dev_scalars.data_ptr(), eps_mode, gscale, ptr(mirror), stream()), "tmi_adam_step_dev")
 
 
 def cast_bf16(src, lds, dst, ldd, rows, cols, src_off=0, dst_off=0):

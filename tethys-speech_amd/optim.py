@@ -29,3 +29,15 @@ class Adam:
         self.iterations += 1
         ops.adam_step(a.p, a.g, a.m, a.v, a.numel, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
                       self.iterations, self.eps_mode, self.weight_decay, grad_scale, mirror=model.mirror)
+
+    # -- captured-graph form: the launch reads its step-dependent scalars from device memory
+    def scalars(self, step=None):
+        return ops.adam_scalars(self.learning_rate, self.beta_1, self.beta_2, self.iterations if step is None else step,
+                                self.eps_mode, self.weight_decay)
+
+    def apply_gradients_dev(self, model, dev_scalars, grad_scale=1.0):
+        """The update of ``apply_gradients`` with [step_size, vcorr, decay] taken from ``dev_scalars``
+        (a 3-float device tensor the caller refreshes from ``scalars()`` before every replay)."""
+        a = model.arena
+        ops.adam_step_dev(a.p, a.g, a.m, a.v, a.numel, self.beta_1, self.beta_2, self.epsilon, dev_scalars,
+                          self.eps_mode, grad_scale, mirror=model.mirror)

@@ -274,6 +274,15 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
 
     # -- forward + backward ----------------------------------------------------------------
     def forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
+        """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
+        ``_forward_backward``."""
+        self.begin_step()
+        try:
+            return self._forward_backward(audio, neg_indices, num_replicas)
+        finally:
+            self.end_step()
+
+    def _forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
         """One replica's V:1199-1240: returns the device scalar ``scaled_loss`` =
         (contrastive + 0.1 * (-perplexity)) / num_replicas; gradients of it land in ``arena.g``."""
         cfg = self.config

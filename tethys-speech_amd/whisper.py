@@ -291,6 +291,16 @@ class WhisperForConditionalGeneration(KernelBlocks):
     # -- forward -------------------------------------------------------------------------
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
                          grad_ready=None):
+        """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
+        ``_forward_backward``."""
+        self.begin_step()
+        try:
+            return self._forward_backward(features, labels, loss_scale, grad_ready)
+        finally:
+            self.end_step()
+
+    def _forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
+                         grad_ready=None):
         """One replica's forward + backward (W:826-833).  features [B, n_mels, T_in] fp32,
         labels [B, S] int32, both on the device.  Gradients land in ``arena.g`` (which is
         zeroed first); returns the device scalar loss (mean over B*(S-1), W:600).
