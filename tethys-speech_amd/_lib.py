@@ -107,6 +107,10 @@ def lib():
         raise TmiError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch's wheel bundles its own libamdhip64: it must be in the process BEFORE this library is
+    # loaded, or the dynamic linker resolves our DT_NEEDED entry to the system copy and the process
+    # ends up with two HIP runtimes (ours then reports "no ROCm-capable device" on its first launch).
+    import torch  # noqa: F401
     h = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
