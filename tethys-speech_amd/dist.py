@@ -45,8 +45,12 @@ def task_from_env(env=None) -> Tuple[str, int, int, int]:
 
 class DataParallelStrategy:
     def __init__(self, rank: int = 0, world: int = 1, backend: Optional[str] = None,
-                 bucket_bytes: int = 64 << 20, init: bool = True):
+                 bucket_bytes: int = 24 << 20, init: bool = True):
         self.rank, self.world = rank, world
+        # launch threshold of the overlapped exchange.  24 MiB: every Whisper small-ref layer (28-38 MB of
+        # fp32 gradients) goes out as soon as it is final, so what remains exposed after backward is
+        # the conv stem's 8 MB, not "last layer + stem" (the big tensors, lm_head / embeddings at 160 MB,
+        # are single collectives either way; xGMI rings are per-link bound, large messages are fine)
         self.bucket_bytes = bucket_bytes
         self._g = None
         self._works: List = []
