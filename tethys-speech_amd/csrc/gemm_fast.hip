@@ -347,7 +347,12 @@ template <> struct Cfg<6> { static constexpr int BM = 64, BN = 64, WM = 32, WN =
 template <> struct Cfg<7> { static constexpr int BM = 128, BN = 128, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
 template <> struct Cfg<8> { static constexpr int BM = 256, BN = 256, WM = 64, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
 template <> struct Cfg<9> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 2; static constexpr bool SPEC = false; };
-template <int CFG> constexpr bool kRegStage = CFG >= 7;
+// CFG 10: CFG 6 with a 4-stage ring and counted vmcnt.  Only when the grid is at most one workgroup
+// per CU (64 KiB of LDS each: co-resident 2-stage workgroups hide latency better when there are
+// enough of them — M800 N3072 K3072: 40 us on CFG 6, 61 us on CFG 10) and K is long (M800 N768 K3072
+// with a k-strided B: 36 -> 30 us).
+template <> struct Cfg<10> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 4; static constexpr bool SPEC = false; };
+template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
 
 // Split-K through the workspace: every split runs the ordinary (non-atomic) epilogue into its own
 // fp32 slab [nbatch][M][N] of the caller's workspace, and splitk_reduce_kernel, launched right
@@ -533,6 +538,34 @@ void gemm_fast_kernel(const FastParams P) {
         __syncthreads();
         buf ^= 1;
       }
+    }
+  } else if constexpr (NSTAGE > 2 && !K::SPEC && ABL == 0) {
+    // Deep ring for latency-bound problems (one small workgroup per CU, nothing else to hide the
+    // DMA round trip behind): tiles t+1 .. t+NSTAGE-1 are in flight while tile t is multiplied.
+    // Counted wait: each wave issues LPT LDS-DMA instructions per tile, in tile order, so
+    // "all but the newest (NSTAGE-2)*LPT" means tile t has landed.  Every slot of the schedule is
+    // issued (past the last tile the last one is re-fetched into a slot nobody reads) to keep that
+    // count exact.  One barrier per K-tile: it publishes tile t and retires the reads of tile t-1,
+    // whose slot the stage issued right after it overwrites.
+    if (nt > 0) {
+      constexpr int LPT = PA + PB;
+      static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
+      const int last = it0 + nt - 1;
+#pragma unroll
+      for (int s_ = 0; s_ < NSTAGE - 1; ++s_) stage(min(it0 + s_, last), s_);
+      int slot = 0, fill = NSTAGE - 1;
+      for (int t = 0; t < nt; ++t) {
+        wait_vmcnt<(NSTAGE - 2) * LPT>();
+        __syncthreads();
+        stage(min(it0 + t + NSTAGE - 1, last), fill);
+        zero_tail(it0 + t, slot);
+        const char* As = smem + slot * STAGE;
+        mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+        slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+        fill = fill + 1 == NSTAGE ? 0 : fill + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetched tail tiles must land before LDS is reused
+      __syncthreads();
     }
   } else
   if (nt > 0) {
@@ -1047,7 +1080,12 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 7) return launch_cfg<TC, A_KS, B_KS, 7>(d, stream);
   if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
   if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
-  if (small) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  if (force == 11) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
+  if (small) {
+    const int64_t tiles64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nbatch;
+    if (force < 0 && tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
+    return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
+  }
   // weight gradients with a large output and a long reduction: eight-phase kernel, split-K through
   // workspace slabs (-13 % against the 128x128 kernel with atomics; smaller outputs lose)
   if constexpr (A_KS && B_KS && sizeof(TC) == 4) {
