@@ -134,8 +134,70 @@ def test_gemm_kbatch_splitk(dev):
 
 
 # ----------------------------------------------------------------------------- LayerNorm etc.
+# Shapes below are chosen to land on the shape-selected fast paths of gemm_fast.hip: the eight-phase
+# 256x256 kernel (k-contiguous A with either B layout; M >= 2048, long K or a light epilogue), its
+# k-strided-A form with split-K through workspace slabs and a K tail (weight gradients, K >= 4096),
+# slab split-K on the 128x128 kernel (>= 64 K-tiles), and the 4-stage 64x64 ring (<= 256 tiles, K >= 1536).
+@pytest.mark.parametrize("M,N,K,b_kn", [(2304, 1544, 1536, False), (4352, 768, 704, False), (2304, 1544, 1600, True),
+                                        (4100, 776, 3008, True)])  # (>= 200 128x128 tiles: not the small-problem path)
+def test_gemm_eight_phase_paths(dev, M, N, K, b_kn):
+    ops = _ops()
+    bf = torch.bfloat16
+    A = rnd((M, K), bf, dev, 11)
+    Bm = rnd((K, N), bf, dev, 12, 0.1)
+    bias = rnd((N,), torch.float32, dev, 13)
+    resid = rnd((M, N), bf, dev, 14)
+    pre = A.double() @ Bm.double() + bias.double()
+    Cm = torch.empty((M, N), dtype=bf, device=dev)
+    if b_kn:  # forward layout: B [K, N], k-strided
+        U = torch.empty_like(Cm)
+        ops.gemm(A, Bm, Cm, M, N, K, K, 1, N, 1, N, bias=bias, act=1, aux_out=U, resid=resid, r_ld=N)
+        ref = torch.tensor(np.vectorize(lambda v: 0.5 * v * (1 + math.erf(v / math.sqrt(2))))(pre.cpu().numpy())).to(dev) \
+            + resid.double()
+        assert rel_err(U, pre) <= 1.5e-2
+    else:     # dgrad layout: B stored [N, K], k-contiguous
+        Bt = Bm.t().contiguous()
+        ops.gemm(A, Bt, Cm, M, N, K, K, 1, 1, K, N, bias=bias, resid=resid, r_ld=N)
+        ref = pre + resid.double()
+    assert rel_err(Cm, ref) <= 1.5e-2
+
+
+@pytest.mark.parametrize("T,Kin,N", [(4128, 768, 2304), (4640, 1544, 1160), (4128, 256, 768), (8200, 128, 384)])
+def test_gemm_weight_gradient_paths(dev, T, Kin, N):
+    """dW[Kin, N] = X^T dY over T tokens (T % 64 = 32 or 8: K tail), library-chosen split-K with the
+    workspace (slabs) — the first two shapes take the eight-phase kernel, the others the 128x128 one."""
+    ops = _ops()
+    bf = torch.bfloat16
+    X = rnd((T, Kin), bf, dev, 21)
+    dY = rnd((T, N), bf, dev, 22)
+    ref = X.double().t() @ dY.double()
+    dW = torch.full((Kin, N), 7.0, dtype=torch.float32, device=dev)   # slabs overwrite: no zeroing needed
+    ops.gemm(X, dY, dW, Kin, N, T, 1, Kin, N, 1, N, splitk=0)
+    assert rel_err(dW, ref) <= 1e-4
+    # accumulate into an existing gradient
+    base = rnd((Kin, N), torch.float32, dev, 23)
+    dW2 = base.clone()
+    ops.gemm(X, dY, dW2, Kin, N, T, 1, Kin, N, 1, N, splitk=0, accumulate=True)
+    assert rel_err(dW2, ref + base.double()) <= 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(800, 768, 3072), (792, 512, 1536), (100, 768, 2304)])
+def test_gemm_deep_ring_small_tiles(dev, M, N, K):
+    ops = _ops()
+    bf = torch.bfloat16
+    A = rnd((M, K), bf, dev, 31)
+    W = rnd((K, N), bf, dev, 32, 0.1)
+    Cm = torch.empty((M, N), dtype=bf, device=dev)
+    ops.gemm(A, W, Cm, M, N, K, K, 1, N, 1, N)                       # k-strided B
+    ref = A.double() @ W.double()
+    assert rel_err(Cm, ref) <= 1.5e-2
+    Wt = W.t().contiguous()
+    ops.gemm(A, Wt, Cm, M, N, K, K, 1, 1, K, N)                      # k-contiguous B
+    assert rel_err(Cm, ref) <= 1.5e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,Cn", [(130, 768), (7, 384), (1000, 1280), (33, 32)])
+@pytest.mark.parametrize("rows,Cn", [(130, 768), (7, 384), (1000, 1280), (33, 32), (513, 512), (65, 1024), (20, 2048), (4100, 768)])
 def test_layernorm(dev, dtype, rows, Cn):
     ops = _ops()
     x = rnd((rows, Cn), dtype, dev, 20, 2.0) + 0.5
