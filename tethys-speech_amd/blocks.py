@@ -254,8 +254,10 @@ class KernelBlocks:
         self._gemm_xw(x2d, wname, out2d, x2d.shape[0], N, K, x2d.stride(0), ldc=out2d.stride(0), n_off=n_off,
                       bias=bias, **epi)
 
-    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None):
-        """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in))."""
+    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False):
+        """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
+        ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
+        before its consumer), so the dgrad goes to the weight-gradient stream too."""
         w, ldw = self.W(wname)
         K_in = w.shape[0]
         N = self.arena.shapes[wname][-1]
@@ -269,11 +271,18 @@ class KernelBlocks:
             if bname in self.arena.offsets:
                 ops.bias_grad(dy2d, self.arena.grad(bname))
 
+        def dgrad():
+            ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
+                     accumulate=accumulate_dx, aux_in=aux_in)
+
+        if dgrad_on_side and dx2d is not None and self._side is not None:
+            self._guard_write(dx2d)
+            self._run_on_side(lambda: (weight_grads(), dgrad()), dy2d)
+            return
         self._run_on_side(weight_grads, dy2d)
         if dx2d is not None:
             self._guard_write(dx2d)
-            ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
-                     accumulate=accumulate_dx, aux_in=aux_in)
+            dgrad()
 
     def _ln_fwd(self, x2d, pname, y2d, stat):
         a = self.arena

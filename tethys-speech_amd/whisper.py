@@ -429,6 +429,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
             kvc, dkvc, dqc = ws[k + "kvc"], ws["dkvc"], ws["dtmp"][:Rd]
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0), (kvc, 0), (kvc, d),
                            ws[k + "ctxc"], dctx, (dqc, 0), (dkvc, 0), (dkvc, d), B, Hd, S, T, 0)
+            # (moving this dgrad to the weight-gradient stream as well — d_enc is only consumed when the
+            # encoder's backward starts — measured slower: 9.65 vs 9.50 ms/step; the side stream is then the longer one)
             self._dense_bwd(enc_out, dkvc, p + ".encoder_attn.kv.kernel", d_enc, accumulate_dx=not first_cross)
             first_cross = False
             dxn2 = ws["dctx"][:Rd]
