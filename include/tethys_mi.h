@@ -300,6 +300,11 @@ int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, const float* me
                              int64_t frames, int32_t n_bins, int32_t n_mels, float eps,
                              int32_t channels_first, int64_t ld_out, void* stream);
 
+/* Diagnostics only: copies the five phase counters of the stamped GEMM build (TMI_GEMM_DBG=8: cycles
+ * spent issuing the LDS-DMA, in MFMA + fragment reads, in the vmcnt wait, in the barrier, and the
+ * iteration count, from one workgroup) to host memory.  Host-synchronous; not part of the data path. */
+int tmi_debug_gemm_stamps(unsigned long long* out5);
+
 #ifdef __cplusplus
 }
 #endif
