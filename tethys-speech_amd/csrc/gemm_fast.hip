@@ -837,6 +837,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   }
 #undef P8_MMA
 
+  if (P.dbg & 1) {  // diagnostics: no epilogue (keep the accumulators live)
+    if (acc[0][0][0] + acc[3][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
+    return;
+  }
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -1001,7 +1005,8 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   const int vecC = 16 / (int)sizeof(TC);
   P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
-  P.dbg = 0;
+  static const int dbg8 = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  P.dbg = dbg8;
   P.split_c_stride = 0;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
