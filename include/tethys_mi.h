@@ -111,6 +111,10 @@ int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N,
 /* dx = dy * gelu_erf'(u), elementwise over n elements (backward of W:336 where the GELU
  * output feeds the positional add rather than a GEMM). */
 int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream);
+/* The same over nbatch spans of n elements whose starts are dy_sb / u_sb / dx_sb elements apart (one
+ * launch for the per-sample spans of a padded buffer). */
+int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
+                         int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Materialised-score softmax (fp32 "parity mode" attention, the reference's own graph

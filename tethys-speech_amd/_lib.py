@@ -60,6 +60,7 @@ SIGNATURES = {
     "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "tmi_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
     "tmi_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "tmi_gelu_bwd_batched": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_softmax_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_softmax_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "tmi_attn_fwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
@@ -91,7 +92,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _lib = None
 
 

@@ -276,8 +276,12 @@ __global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const T* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
-                                                       T* __restrict__ dx, int64_t nvec) {
+                                                       T* __restrict__ dx, int64_t nvec, int64_t dy_sb, int64_t u_sb,
+                                                       int64_t dx_sb) {
   constexpr int VEC = 16 / sizeof(T);
+  dy += (int64_t)blockIdx.y * dy_sb;  // batch (blockIdx.y) strides in elements, multiples of VEC
+  u += (int64_t)blockIdx.y * u_sb;
+  dx += (int64_t)blockIdx.y * dx_sb;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
     const u32x4 b = reinterpret_cast<const u32x4*>(u)[i];
@@ -386,23 +390,31 @@ extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, 
   return tmi_check_launch("tmi_colsum");
 }
 
-extern "C" int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream) {
+extern "C" int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
+                                    int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!dy || !u || !dx || n <= 0 || n % vec || !al16(dy) || !al16(u) || !al16(dx)) {
+  if (!dy || !u || !dx || n <= 0 || nbatch <= 0 || nbatch > 65535 || n % vec || dy_sb % vec || u_sb % vec || dx_sb % vec ||
+      !al16(dy) || !al16(u) || !al16(dx)) {
     tmi_set_error("tmi_gelu_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t nvec = n / vec;
   int64_t blocks = (nvec + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  const int64_t cap = 4096 / nbatch > 0 ? 4096 / nbatch : 1;
+  if (blocks > cap) blocks = cap;
+  dim3 grid((unsigned)blocks, (unsigned)nbatch);
   if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)dy,
-                       (const bf16_t*)u, (bf16_t*)dx, nvec);
+    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, nvec,
+                       dy_sb, u_sb, dx_sb);
   else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)dy,
-                       (const float*)u, (float*)dx, nvec);
+    hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)u, (float*)dx, nvec,
+                       dy_sb, u_sb, dx_sb);
   else
     return TMI_ERR_UNSUPPORTED;
   return tmi_check_launch("tmi_gelu_bwd");
+}
+
+extern "C" int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream) {
+  return tmi_gelu_bwd_batched(dy, u, dx, n, 1, 0, 0, 0, dtype, stream);
 }

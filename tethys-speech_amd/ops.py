@@ -152,6 +152,12 @@ def gelu_bwd(dy, u, dx):
           "tmi_gelu_bwd")
 
 
+def gelu_bwd_batched(dy, u, dx, n, nbatch, dy_sb, u_sb, dx_sb):
+    """nbatch spans of n elements, batch strides in elements (tensors give the base pointers)."""
+    check(lib().tmi_gelu_bwd_batched(dy.data_ptr(), u.data_ptr(), dx.data_ptr(), n, nbatch, dy_sb, u_sb, dx_sb, dt(dy),
+                                     stream()), "tmi_gelu_bwd")
+
+
 def softmax_fwd(s, rows, Tq, Tk, mask_mode):
     check(lib().tmi_softmax_fwd(s.data_ptr(), rows, Tq, Tk, mask_mode, stream()), "tmi_softmax_fwd")
 

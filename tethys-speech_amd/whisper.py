@@ -471,11 +471,10 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # ---- stem backward: x0 = gelu(u2) + PE ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(x)
         du2pad, dh1pad = ws["du2pad"], ws["dh1pad"]
         du2 = du2pad[:, 1:]  # row 0 of every batch stays zero (the "t-1" term of the first output)
-        for b in range(B):  # gelu_bwd needs contiguous spans: one per batch
-            ops.gelu_bwd(dres[b * T:(b + 1) * T], ws["u2"][b], du2[b])
-        gb2 = a.grad("encoder.conv2.bias")
-        for b in range(B):
-            ops.bias_grad(du2[b], gb2)
+        # one launch over the B per-sample spans (du2 skips the zero row 0 of every sample)
+        ops.gelu_bwd_batched(dres, ws["u2"], du2, T * d, B, T * d, T * d, du2pad.stride(0))
+        # the pad rows of du2pad are zero, so the bias gradient is one column sum over the whole buffer
+        ops.bias_grad(du2pad.view(-1, d), a.grad("encoder.conv2.bias"))
         gw2 = a.grad("encoder.conv2.kernel").view(3 * d, d)
         ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
                  b_skb=du2pad.stride(0), b_off=d, splitk=0)
@@ -489,9 +488,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         if self.pl2:
             dh1pad[:, :self.pl2].zero_()
         dh1pad[:, self.pl2 + self.T1:].zero_()
-        gb1 = a.grad("encoder.conv1.bias")
-        for b in range(B):
-            ops.bias_grad(dh1pad[b, self.pl2:self.pl2 + self.T1], gb1)
+        ops.bias_grad(dh1pad.view(-1, d), a.grad("encoder.conv1.bias"))  # (pad rows were just zeroed)
         gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),
                  b_skb=dh1pad.stride(0), b_off=self.pl2 * d, splitk=0)
