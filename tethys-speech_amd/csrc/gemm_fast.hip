@@ -308,6 +308,91 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
   }
 }
 
+// The same epilogue for ONE 32x32 accumulator block through a 4 KiB staging image (configurations
+// whose waves own 32x32 outputs): rows of 32 fp32, 16-byte chunks XOR-swizzled by (row & 7);
+// 4 lanes x 8 columns per row, 16 rows per pass.
+__device__ __forceinline__ int epi32_off(int row, int col) { return row * 128 + ((((col >> 2) ^ (row & 7)) << 4) | ((col & 3) << 2)); }
+
+template <typename TC>
+__device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x16& a0, char* E, int64_t mw, int64_t nw,
+                                                int64_t bz, int lane) {
+  const tmi_gemm_desc& d = P.d;
+  {
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      *reinterpret_cast<float*>(E + epi32_off(row, c)) = a0[reg];
+    }
+  }
+  TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb + (int64_t)blockIdx.y * P.split_c_stride;
+  TC* aux_out = d.aux_out ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb : nullptr;
+  const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
+  const TC* resid = d.resid ? reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb : nullptr;
+  const int chunk = lane & 3;
+  const int64_t n = nw + chunk * 8;
+  if (n >= d.N) return;
+  const bool full = P.wide && (n + 8 <= d.N);
+  float bv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[bz * d.bias_sb + n + i] : 0.f;
+#pragma unroll 1
+  for (int p = 0; p < 2; ++p) {
+    const int row = p * 16 + (lane >> 2);
+    const int64_t m = mw + row;
+    if (m >= d.M) continue;
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(E + epi32_off(row, chunk * 8));
+      const f32x4 b = *reinterpret_cast<const f32x4*>(E + epi32_off(row, chunk * 8 + 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    const int64_t idx = m * d.ldc + n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] += bv[i];
+      if (n + i < d.scale_cols) v[i] *= d.scale;
+    }
+    if (full) {
+      float t[8];
+      if (d.accumulate) {
+        Vec8<TC>::load(C + idx, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+      }
+      if (aux_out) Vec8<TC>::store(aux_out + idx, v);
+      if (d.act == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
+      }
+      if (aux_in) {
+        Vec8<TC>::load(aux_in + idx, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
+      }
+      if (resid) {
+        Vec8<TC>::load(resid + m * d.r_ld + n, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += t[i];
+      }
+      Vec8<TC>::store(C + idx, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (n + i >= d.N) break;
+        float x = v[i];
+        if (d.accumulate) x += to_f32(C[idx + i]);
+        if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
+        if (d.act == 1) x = gelu_fwd_t<TC>(x);
+        if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
+        if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
+        C[idx + i] = from_f32<TC>(x);
+      }
+    }
+  }
+}
+
 __device__ unsigned long long g_gemm_stamps[8];  // diagnostics (ABL == 8): cycles per loop phase, block 0 wave 0
 
 __device__ __forceinline__ unsigned long long stamp() {
@@ -352,6 +437,12 @@ template <> struct Cfg<9> { static constexpr int BM = 64, BN = 64, WM = 32, WN =
 // enough of them — M800 N3072 K3072: 40 us on CFG 6, 61 us on CFG 10) and K is long (M800 N768 K3072
 // with a k-strided B: 36 -> 30 us).
 template <> struct Cfg<10> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 64, NSTAGE = 4; static constexpr bool SPEC = false; };
+// CFG 11: the 64x64 tile on FOUR waves of 32x32 (all four SIMDs of the CU, half the fragment-read + MFMA
+// chain per K-tile per wave): for grids of at most ~one workgroup per CU, where the K loop of CFG 6 is a
+// latency chain on two SIMDs.  Never split (its epilogue has no atomic form).
+template <> struct Cfg<11> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 2; static constexpr bool SPEC = false; };
+// CFG 12: CFG 11 with the 4-stage ring of CFG 10
+template <> struct Cfg<12> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
 template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
 
 // Split-K through the workspace: every split runs the ordinary (non-atomic) epilogue into its own
@@ -590,12 +681,20 @@ void gemm_fast_kernel(const FastParams P) {
     if (acc[0][0][0] + acc[MI - 1][NI - 1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;  // keep acc live
     return;
   }
+  if constexpr (NI == 1) {  // 32x32 per wave: the 32-column epilogue, 4 KiB of staging per wave
+    char* E32 = smem + wave * 4096;
+#pragma unroll
+    for (int p = 0; p < MI; ++p)
+      wide_epilogue32<TC>(P, acc[p][0], E32, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane);
+    return;
+  } else {
   static_assert(NI == 2, "epilogue pieces are 64 columns wide");
   const bool atomic = nsplit > 1;
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int p = 0; p < MI; ++p)
     wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, atomic);
+  }
 }
 
 // =====================================================================================
@@ -881,7 +980,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   using K = Cfg<CFG>;
   constexpr int NW = (K::BM / K::WM) * (K::BN / K::WN);
   constexpr int LDS_BYTES = K::NSTAGE * (K::BM + K::BN) * 128;
-  static_assert(LDS_BYTES >= NW * 8192, "epilogue staging must fit the ring");
+  static_assert(LDS_BYTES >= NW * (K::WN == 32 ? 4096 : 8192), "epilogue staging must fit the ring");
   FastParams P;
   P.d = d;
   P.tiles_m = (int)((d.M + K::BM - 1) / K::BM);
@@ -972,6 +1071,10 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     if (use_ws && want * slab_bytes > d.workspace_bytes) use_ws = false;
     if (use_ws && want > 1) ws_split = true;
     splitk = want < 1 ? 1 : (int)want;
+  }
+  if (K::WN == 32) {
+    splitk = 1;
+    ws_split = false;
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
   if (ws_split) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
@@ -1086,9 +1189,17 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
   if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
   if (force == 11) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
+  if (force == 12 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
+  if (force == 13 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
   if (small) {
+    // measured (tools/gemm_small.py, M = 800): four waves of 32x32 beat two of 32x64 wherever the grid is
+    // at most one workgroup per CU (N 768, K 768: 12.3 -> 9.1 us) and tie elsewhere; the 4-stage ring adds
+    // to that for long K on such grids (N 768, K 3072: 27.4 -> 21.4 us) and loses co-residency on larger ones
     const int64_t tiles64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nbatch;
-    if (force < 0 && tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
+    if (d.splitk <= 1) {
+      if (tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
+      return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
+    }
     return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
   }
   // weight gradients with a large output and a long reduction: eight-phase kernel, split-K through
