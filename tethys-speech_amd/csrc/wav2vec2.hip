@@ -43,14 +43,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     rstd = stats[(b * G + g) * 2 + 1];
   }
   if (threadIdx.x < cpr * rstep) {
-    for (int r = r0 + threadIdx.x / cpr; r < r1; r += rstep) {
-      const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (int64_t)b * xsb + (int64_t)r * C + c0);
+    auto one = [&](const u32x4& raw, const u32x4& rawd) {
       const T* e = reinterpret_cast<const T*>(&raw);
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { const float v = to_f32(e[i]); a += v; bsum += v * v; }
       } else {
-        const u32x4 rawd = *reinterpret_cast<const u32x4*>(dy + (int64_t)b * dysb + (int64_t)r * C + c0);
         const T* ed = reinterpret_cast<const T*>(&rawd);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -61,15 +59,44 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
           bsum += dz * gm[i] * xh;
         }
       }
+    };
+    const T* xb = x + (int64_t)b * xsb + c0;
+    const T* db = MODE == 1 ? dy + (int64_t)b * dysb + c0 : nullptr;
+    int r = r0 + threadIdx.x / cpr;
+    // four row loads in flight per thread (the chunk is a short stream: latency, not bandwidth, bounds it)
+    for (; r + 3 * rstep < r1; r += 4 * rstep) {
+      u32x4 raw[4], rawd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        raw[u] = *reinterpret_cast<const u32x4*>(xb + (int64_t)(r + u * rstep) * C);
+        if (MODE == 1) rawd[u] = *reinterpret_cast<const u32x4*>(db + (int64_t)(r + u * rstep) * C);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(raw[u], rawd[u]);
+    }
+    for (; r < r1; r += rstep) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xb + (int64_t)r * C);
+      u32x4 rawd = raw;
+      if (MODE == 1) rawd = *reinterpret_cast<const u32x4*>(db + (int64_t)r * C);
+      one(raw, rawd);
     }
   }
   sa[threadIdx.x] = a;
   sb[threadIdx.x] = bsum;
   __syncthreads();
-  if (threadIdx.x < G) {  // fixed-order fold of the threads that belong to group threadIdx.x
+  // fixed-order fold in two parallel levels: over the rstep row lanes of each vector column, then over
+  // the Cg / VEC columns of each group
+  if (threadIdx.x < cpr) {
+    float ta = sa[threadIdx.x], tb = sb[threadIdx.x];
+    for (int k = 1; k < rstep; ++k) { ta += sa[threadIdx.x + k * cpr]; tb += sb[threadIdx.x + k * cpr]; }
+    sa[threadIdx.x] = ta;
+    sb[threadIdx.x] = tb;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int per = Cg / VEC;  // vector columns per group
     float ta = 0.f, tb = 0.f;
-    for (int t = 0; t < cpr * rstep; ++t)
-      if (((t % cpr) * VEC) / Cg == (int)threadIdx.x) { ta += sa[t]; tb += sb[t]; }
+    for (int t = 0; t < per; ++t) { ta += sa[threadIdx.x * per + t]; tb += sb[threadIdx.x * per + t]; }
     float* o = part + (((int64_t)b * nchunks + chunk) * G + threadIdx.x) * 2;
     o[0] = ta;
     o[1] = tb;
@@ -77,17 +104,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 }
 
 // fold chunk partials in double.  mode 0: -> (mean, rstd);  mode 1: -> (mean(dxhat), mean(dxhat*xhat))
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int BG, int G,
-                                   int nchunks, double count, float eps, int mode) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int BG,
+                                                         int G, int nchunks, double count, float eps, int mode) {
+  // one wave per (batch, group): lanes stride over the chunks, then a shuffle fold (fixed order)
+  const int i = blockIdx.x;
   if (i >= BG) return;
   const int b = i / G, g = i % G;
   double a = 0.0, s = 0.0;
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = threadIdx.x; c < nchunks; c += 64) {
     const float* p = part + (((int64_t)b * nchunks + c) * G + g) * 2;
     a += p[0];
     s += p[1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    s += __shfl_xor(s, o, 64);
+  }
+  if (threadIdx.x != 0) return;
   if (mode == 0) {
     const double mean = a / count;
     double var = s / count - mean * mean;
@@ -111,19 +145,32 @@ __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* __restrict__
   const int b = blockIdx.y;
   const int Cg = C / G;
   const int64_t nvec = (int64_t)Tn * C / VEC;
-  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * 256) {
-    const int64_t e0 = v * VEC;
-    const int c0 = (int)(e0 % C);
-    const int g = c0 / Cg;
-    const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-    const u32x4 raw = *reinterpret_cast<const u32x4*>(x + (int64_t)b * xsb + e0);
+  // 256 * VEC is a multiple of C (gn_check), so a thread keeps its channels across the grid-stride loop:
+  // gamma / beta / statistics are loaded once
+  const int c0 = (int)(((int64_t)threadIdx.x * VEC) % C);
+  const int g = c0 / Cg;
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  float gm[VEC], bt[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
+  const T* xb = x + (int64_t)b * xsb;
+  T* yb = y + (int64_t)b * ysb;
+  const int64_t step = (int64_t)gridDim.x * 256;
+  auto one = [&](const u32x4& raw, int64_t v) {
     const T* e = reinterpret_cast<const T*>(&raw);
     alignas(16) T o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i)
-      o[i] = from_f32<T>(gelu_fwd_t<T>(gamma[c0 + i] * ((to_f32(e[i]) - mean) * rstd) + beta[c0 + i]));
-    *reinterpret_cast<u32x4*>(y + (int64_t)b * ysb + e0) = *reinterpret_cast<const u32x4*>(o);
+    for (int i = 0; i < VEC; ++i) o[i] = from_f32<T>(gelu_fwd_t<T>(gm[i] * ((to_f32(e[i]) - mean) * rstd) + bt[i]));
+    *reinterpret_cast<u32x4*>(yb + v * VEC) = *reinterpret_cast<const u32x4*>(o);
+  };
+  int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; v + step < nvec; v += 2 * step) {
+    const u32x4 r0 = *reinterpret_cast<const u32x4*>(xb + v * VEC);
+    const u32x4 r1 = *reinterpret_cast<const u32x4*>(xb + (v + step) * VEC);
+    one(r0, v);
+    one(r1, v + step);
   }
+  if (v < nvec) one(*reinterpret_cast<const u32x4*>(xb + v * VEC), v);
 }
 
 // backward apply: dx = rstd * (dxhat - m1 - xhat * m2), dxhat = dz * gamma; dgamma += dz*xhat, dbeta += dz
@@ -426,8 +473,10 @@ template <typename T> struct Launch {
   else return TMI_ERR_UNSUPPORTED;
 
 extern "C" int64_t tmi_groupnorm_chunks(int64_t T) {
+  // row chunks per sample.  At most 32: every chunk's workgroup ends with one fp32 atomic per channel into
+  // dgamma / dbeta, and same-address atomics serialise (~20 ns each); B * 32 workgroups still fill the chip
   int64_t n = (T + 63) / 64;
-  if (n > 256) n = 256;
+  if (n > 32) n = 32;
   return n < 1 ? 1 : n;
 }
 
@@ -455,7 +504,7 @@ extern "C" int tmi_groupnorm_gelu_fwd(const void* x, int64_t x_sb, const float* 
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 0>), gp, dim3(256), 0, s, (const bf16_t*)x, x_sb, (const bf16_t*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((gn_partial_kernel<float, 0>), gp, dim3(256), 0, s, (const float*)x, x_sb, (const float*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((B * G + 63) / 64)), dim3(64), 0, s, part, stats, (int)(B * G),
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, stats, (int)(B * G),
                      (int)G, nch, (double)T * (double)(C / G), eps, 0);
   int64_t blocks = (T * C / vec + 255) / 256;
   if (blocks > 1024) blocks = 1024;
@@ -483,7 +532,7 @@ extern "C" int tmi_groupnorm_gelu_bwd(const void* x, int64_t x_sb, const void* d
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 1>), gp, dim3(256), 0, s, (const bf16_t*)x, x_sb, (const bf16_t*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((gn_partial_kernel<float, 1>), gp, dim3(256), 0, s, (const float*)x, x_sb, (const float*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((B * G + 63) / 64)), dim3(64), 0, s, part, sums, (int)(B * G),
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, sums, (int)(B * G),
                      (int)G, nch, (double)T * (double)(C / G), 0.f, 1);
   const int cpr = (int)C / vec;
   const int rstep = 256 / cpr > 0 ? 256 / cpr : 1;
