@@ -185,14 +185,18 @@ def main():
         # duration is its own (in the timed region above weight gradients overlap the dgrad chain).
         overlap = model._side is not None
         model.enable_wgrad_stream(False)
-        ops.PROFILE = ops.GemmProfile()
+        # One step per probe object, read out before the next: with more than ~500 timing events
+        # outstanding the runtime stalls the stream for ~50 ms on a record, which is not GEMM time.
         nprof = min(args.steps, 3)
+        ms = flops = launches = 0
         for _ in range(nprof):
+            ops.PROFILE = ops.GemmProfile()
             one_step()
-        torch.cuda.synchronize()
-        prof, ops.PROFILE = ops.PROFILE, None
+            torch.cuda.synchronize()
+            prof, ops.PROFILE = ops.PROFILE, None
+            m_, f_, l_ = prof.totals()
+            ms, flops, launches = ms + m_, flops + f_, launches + l_
         model.enable_wgrad_stream(overlap)
-        ms, flops, launches = prof.totals()
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic cannot be counted from inside the process: it comes from the last committed PMC
         # passes over this same command (tools/pmc_traffic.py), bytes per tmi_gemm launch
