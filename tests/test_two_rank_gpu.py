@@ -1,0 +1,94 @@
+"""The N > 1 training step on a GPU: two ranks (gloo moves the CUDA gradient buckets; RCCL cannot put two
+ranks on one device) share cuda:0 and run ``distributed_train_step`` with small buckets, so the overlapped
+exchange (ranges reported during backward, weight-gradient stream joined before every launch, async works
+waited before Adam) is exercised end to end.  Reference semantics (W:829-836): gradients are SUMMED over
+replicas, no 1/N; both ranks must end with identical parameters, equal to one process that accumulates both
+shards' gradients and applies Adam once per step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(d_model=128, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=256, vocab_size=160,
+          encoder_layers=2, decoder_layers=2, n_mels=16, n_ctx=32, decoder_start_token_id=150, max_target_positions=32)
+STEPS = 3
+
+
+def _batches():
+    rng = np.random.default_rng(7)
+    return [[(rng.standard_normal((2, 16, 48)).astype(np.float32), rng.integers(0, 150, (2, 12)).astype(np.int32))
+             for _ in range(STEPS)] for _ in range(2)]  # [rank][step]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train, whisper
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=256 * 1024)
+    model = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=11 + rank, **KW)  # differ per rank
+    strat.broadcast_parameters(model.arena.p)  # C4: everyone starts from rank 0's values
+    model.refresh_shadows()
+    opt = optim.Adam(1e-3)
+    losses = []
+    launched = 0
+    for f, l in _batches()[rank]:
+        out = train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)), opt)
+        losses.append(float(out.item()))
+    torch.cuda.synchronize()
+    q.put((rank, model.arena.p.cpu().numpy(), losses))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_accumulated_single_process(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, p0, l0), (_, p1, l1) = res
+    assert np.array_equal(p0, p1), "replicas diverged"
+    assert l0 == l1  # C2: the reduced (summed) loss is the same on every rank
+
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import optim, whisper
+    model = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=11, **KW)
+    opt = optim.Adam(1e-3)
+    b = _batches()
+    ref_losses = []
+    for s in range(STEPS):
+        tot = torch.zeros_like(model.arena.g)
+        lsum = 0.0
+        for r in range(2):
+            f, l = b[r][s]
+            loss = model.forward_backward(torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev))
+            tot += model.arena.g
+            lsum += float(loss.item())
+        model.arena.g.copy_(tot)
+        opt.apply_gradients(model)
+        ref_losses.append(lsum)
+    ref = model.arena.p.cpu().numpy()
+    assert np.allclose(l0, ref_losses, rtol=1e-5, atol=1e-6), (l0, ref_losses)
+    err = np.abs(p0 - ref).max() / np.abs(ref).max()
+    assert err <= 1e-5, err
