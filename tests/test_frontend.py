@@ -40,6 +40,15 @@ def test_oracle_tone_and_shapes():
     assert np.isclose(p[0] + p[-1] + 2 * p[1:-1].sum(), 400 * np.sum(fr ** 2))
 
 
+def test_host_constants_match_the_restatement():
+    """The product's host-side constants (built once in fp64) against the oracle's, without a GPU."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import frontend as F
+    assert np.allclose(F.mel_weight_matrix(), L.linear_to_mel_weight_matrix(), rtol=0, atol=1e-15)
+    assert np.allclose(F.hann_periodic(400), L.hann_periodic(400), rtol=0, atol=1e-15)
+    assert F.mel_weight_matrix(40, 129, 8000, 0.0, 4000.0).shape == (129, 40)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,N", [(1, 16000), (3, 480000 // 10), (2, 401)])
 def test_frontend_matches_oracle(dev, B, N):
