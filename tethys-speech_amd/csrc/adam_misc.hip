@@ -146,7 +146,9 @@ extern "C" int tmi_adam_step(float* p, const float* g, float* m, float* v, int64
   const float decay = 1.0f - lr * weight_decay;
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 8192) blocks = 8192;
+  // two workgroups per CU stream the arena faster than thousands (measured: 0.83 vs 1.17 ms on 148 M parameters)
+  static const int64_t cap = [] { const char* e = getenv("TMI_ADAM_BLOCKS"); return e ? atoll(e) : 512ll; }();
+  if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
                      m, v, n, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale,
                      (bf16_t*)bf16_mirror, (const float*)nullptr);
@@ -186,7 +188,7 @@ extern "C" int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, i
   }
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g,
                      m, v, n, beta1, beta2, eps, 0.f, 1.f, eps_mode, 1.f, gscale, (bf16_t*)bf16_mirror, dev_scalars);
   return tmi_check_launch("tmi_adam_step_dev");

@@ -422,12 +422,21 @@ __global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restr
   float acc = 0.f;
   const bool vec = (lo & 3) == 0;
   const int64_t nv = vec && b > a ? (b - a) / 4 : 0;
-  for (int64_t i = threadIdx.x; i < nv; i += 256) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(g + a)[i];
+  const f32x4* gv = reinterpret_cast<const f32x4*>(g + a);
+  int64_t i = threadIdx.x;
+  for (; i + 768 < nv; i += 1024) {  // four 16-byte loads in flight per thread
+    const f32x4 v0 = gv[i], v1 = gv[i + 256], v2 = gv[i + 512], v3 = gv[i + 768];
+    acc += v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3];
+    acc += v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3];
+    acc += v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3];
+    acc += v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3];
+  }
+  for (; i < nv; i += 256) {
+    const f32x4 v = gv[i];
     acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
-  for (int64_t i = a + nv * 4 + threadIdx.x; i < b; i += 256) {
-    const float v = g[i];
+  for (int64_t j = a + nv * 4 + threadIdx.x; j < b; j += 256) {
+    const float v = g[j];
     acc += v * v;
   }
   acc = block_sum_256(acc, red);
@@ -446,12 +455,19 @@ __global__ __launch_bounds__(256) void segment_clip_kernel(float* __restrict__ g
   const int64_t a = lo + per * blockIdx.y, b = min(hi, a + per);
   const bool vec = (lo & 3) == 0;
   const int64_t nv = vec && b > a ? (b - a) / 4 : 0;
-  for (int64_t i = threadIdx.x; i < nv; i += 256) {
-    f32x4 v = reinterpret_cast<f32x4*>(g + a)[i];
-    v *= scale;
-    reinterpret_cast<f32x4*>(g + a)[i] = v;
+  f32x4* gv = reinterpret_cast<f32x4*>(g + a);
+  int64_t i = threadIdx.x;
+  for (; i + 768 < nv; i += 1024) {
+    f32x4 v0 = gv[i], v1 = gv[i + 256], v2 = gv[i + 512], v3 = gv[i + 768];
+    v0 *= scale; v1 *= scale; v2 *= scale; v3 *= scale;
+    gv[i] = v0; gv[i + 256] = v1; gv[i + 512] = v2; gv[i + 768] = v3;
   }
-  for (int64_t i = a + nv * 4 + threadIdx.x; i < b; i += 256) g[i] *= scale;
+  for (; i < nv; i += 256) {
+    f32x4 v = gv[i];
+    v *= scale;
+    gv[i] = v;
+  }
+  for (int64_t j = a + nv * 4 + threadIdx.x; j < b; j += 256) g[j] *= scale;
 }
 
 // out[0] = (isnan(a) ? 0 : a + w * b) * scale     (V:1220-1231: loss assembly on the device)
@@ -641,7 +657,7 @@ extern "C" int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* 
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(out, 0, (size_t)nseg * sizeof(float), s) != hipSuccess) return TMI_ERR_LAUNCH;
-  const unsigned split = nseg == 1 ? 1024u : 16u;
+  const unsigned split = nseg == 1 ? 512u : 16u;  // (every block ends with an atomic on out[s])
   hipLaunchKernelGGL(segment_sumsq_kernel, dim3((unsigned)nseg, split), dim3(256), 0, s, g, seg_off, out);
   return tmi_check_launch("tmi_segment_sumsq");
 }
@@ -652,7 +668,7 @@ extern "C" int tmi_segment_clip(float* g, const int64_t* seg_off, const float* s
     tmi_set_error("tmi_segment_clip: bad argument");
     return TMI_ERR_INVALID;
   }
-  const unsigned split = nseg == 1 ? 1024u : 16u;
+  const unsigned split = nseg == 1 ? 512u : 16u;
   hipLaunchKernelGGL(segment_clip_kernel, dim3((unsigned)nseg, split), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), g, seg_off, sumsq, clip);
   return tmi_check_launch("tmi_segment_clip");
