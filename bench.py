@@ -16,6 +16,9 @@ Also reported on the same JSON line:
                 recorded on the launch stream during an instrumented pass of the same steps
                 (weight-gradient side stream off, so launches do not overlap), against the
                 2.5 PFLOP/s dense bf16 MFMA peak.
+  roofline_classes  the same measurement for every instrumented kernel class (GEMM and fused attention
+                against the MFMA peak by algorithmic flop; Adam, LayerNorm, bias column sums and the
+                cross-entropy against the 8 TB/s HBM peak by algorithmic bytes).
   cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the
                 host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up +
                 2 timed steps of the same model and clip length).
@@ -32,6 +35,7 @@ if ROOT not in sys.path:
 
 CLIP_SECONDS = 30.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # HBM3E peak (same guide; ~6.3 TB/s is what streams reach)
 GF_PER_SAMPLE = 449.1           # fwd+bwd algorithmic GFLOP per 30 s sample, small-ref
 
 
@@ -188,15 +192,27 @@ def main():
         # One step per probe object, read out before the next: with more than ~500 timing events
         # outstanding the runtime stalls the stream for ~50 ms on a record, which is not GEMM time.
         nprof = min(args.steps, 3)
-        ms = flops = launches = 0
+        ops.PROFILE = ops.OpProfile()
         for _ in range(nprof):
-            ops.PROFILE = ops.GemmProfile()
             one_step()
-            torch.cuda.synchronize()
-            prof, ops.PROFILE = ops.PROFILE, None
-            m_, f_, l_ = prof.totals()
-            ms, flops, launches = ms + m_, flops + f_, launches + l_
+            ops.PROFILE.flush()
+        prof, ops.PROFILE = ops.PROFILE, None
+        ms, flops, launches = prof.totals("gemm")
         model.enable_wgrad_stream(overlap)
+        # the other kernel classes, each against the roof that bounds it ("report per kernel class")
+        classes = []
+        for cls, bound, peak, unit, scale in (("gemm", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12),
+                                              ("attention", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12),
+                                              ("adam", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                              ("layernorm", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                              ("colsum", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                              ("xent", "hbm", HBM_PEAK_GBS, "GB/s", 1e9)):
+            cm, cw, cn = prof.totals(cls)
+            if cn == 0 or cm <= 0:
+                continue
+            ach = cw / (cm * 1e-3) / scale
+            classes.append({"class": cls, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                            "ms_per_step": cm / nprof, "launches_per_step": cn / nprof})
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM traffic cannot be counted from inside the process: it comes from the last committed PMC
         # passes over this same command (tools/pmc_traffic.py), bytes per tmi_gemm launch
@@ -231,6 +247,7 @@ def main():
         }
         if roof is not None:
             out["roofline"] = roof
+            out["roofline_classes"] = classes
         if world == 1 and not args.no_cpu_baseline:
             log("timing the restated reference CPU path (oracle) on the host cores")
             out["cpu_baseline"] = cpu_baseline(args.model_type, 3000)

@@ -969,7 +969,8 @@ int launch_with_slabs(const FastParams& P, int splitk, hipStream_t stream, F&& l
   const int vec_ok = d.N % 4 == 0 && d.ldc % 4 == 0 && d.c_sb % 4 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
   const int64_t n = d.nbatch * d.M * d.N;
   int64_t blocks = (n / 4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  static const int64_t rcap = [] { const char* e = getenv("TMI_REDUCE_BLOCKS"); return e ? atoll(e) : 2048ll; }();
+  if (blocks > rcap) blocks = rcap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
                      reinterpret_cast<const float*>(d.workspace), splitk, Q.split_c_stride, C, d.M, d.N, d.ldc, d.c_sb,

@@ -43,19 +43,62 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-class GemmProfile:
-    """bench.py's roofline probe: HIP events (on the launch stream) around every tmi_gemm
-    launch plus its algorithmic FLOPs (2*M*N*K*nbatch*kbatch)."""
+class OpProfile:
+    """bench.py's roofline probe: HIP events (recorded on the launch stream) around every wrapped launch,
+    folded per kernel class together with the launch's ALGORITHMIC work (flop for the MFMA classes, bytes
+    for the HBM classes).  Events are read out every ``flush_every`` records: with ~500 timing events
+    outstanding the runtime stalls the stream for tens of milliseconds on a record."""
 
-    def __init__(self):
+    def __init__(self, flush_every=160):
+        self.records = []
+        self.flush_every = flush_every
+        self.acc = {}  # class -> [ms, work, launches]
+
+    def add(self, cls, e0, e1, work):
+        self.records.append((cls, e0, e1, work))
+        if len(self.records) >= self.flush_every:
+            self.flush()
+
+    def flush(self):
+        if not self.records:
+            return
+        torch.cuda.synchronize()
+        for cls, a, b, w in self.records:
+            t = self.acc.setdefault(cls, [0.0, 0.0, 0])
+            t[0] += a.elapsed_time(b)
+            t[1] += w
+            t[2] += 1
         self.records = []
 
-    def totals(self):
-        ms = sum(a.elapsed_time(b) for a, b, _ in self.records)
-        return ms, sum(f for _, _, f in self.records), len(self.records)
+    def totals(self, cls="gemm"):
+        self.flush()
+        ms, work, n = self.acc.get(cls, [0.0, 0.0, 0])
+        return ms, work, n
 
 
-PROFILE = None  # set to a GemmProfile() to instrument
+GemmProfile = OpProfile  # (earlier name)
+PROFILE = None  # set to an OpProfile() to instrument
+
+
+class _probe:
+    """``with _probe(cls, work):`` times the launches inside it when a profile is installed."""
+    __slots__ = ("cls", "work", "e0")
+
+    def __init__(self, cls, work):
+        self.cls, self.work, self.e0 = cls, work, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.add(self.cls, self.e0, e1, self.work)
+        return False
 
 
 _WORKSPACE = {}
@@ -105,11 +148,8 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     if PROFILE is None:
         check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
-    e1.record()
-    PROFILE.records.append((e0, e1, 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch)))
+    with _probe("gemm", 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch)):
+        check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
 
 
 def linear(x2d, w, out, *, w_is_kn=True, **kw):
@@ -126,25 +166,28 @@ def linear(x2d, w, out, *, w_is_kn=True, **kw):
 
 
 def layernorm_fwd(x2d, gamma, beta, y2d, mean, rstd, eps):
-    rows, Cn = x2d.shape
-    check(lib().tmi_layernorm_fwd(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y2d.data_ptr(),
-                                  mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps, dt(x2d), stream()),
-          "tmi_layernorm_fwd")
+    with _probe("layernorm", 2.0 * x2d.numel() * x2d.element_size()):
+        rows, Cn = x2d.shape
+        check(lib().tmi_layernorm_fwd(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y2d.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), rows, Cn, eps, dt(x2d), stream()),
+              "tmi_layernorm_fwd")
 
 
 def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, accumulate_dx=False):
     """dgamma / dbeta are accumulated (atomics): zero them first (the grad arena is)."""
-    rows, Cn = x2d.shape
-    check(lib().tmi_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                  rstd.data_ptr(), dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
-                                  1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
+    with _probe("layernorm", (4.0 if accumulate_dx else 3.0) * x2d.numel() * x2d.element_size()):
+        rows, Cn = x2d.shape
+        check(lib().tmi_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
+                                      1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
 
 
 def bias_grad(dy2d, dbias):
     """dbias[N] += sum over rows of dy2d[rows, N] (atomics: zero dbias first)."""
-    rows, N = dy2d.shape
-    check(lib().tmi_colsum(dy2d.data_ptr(), dy2d.stride(0), dbias.data_ptr(), rows, N, dt(dy2d), stream()),
-          "tmi_colsum")
+    with _probe("colsum", 1.0 * dy2d.numel() * dy2d.element_size()):
+        rows, N = dy2d.shape
+        check(lib().tmi_colsum(dy2d.data_ptr(), dy2d.stride(0), dbias.data_ptr(), rows, N, dt(dy2d), stream()),
+              "tmi_colsum")
 
 
 def gelu_bwd(dy, u, dx):
@@ -181,8 +224,9 @@ def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale=1.0):
 
 
 def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0):
-    d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
-    check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
+    with _probe("attention", 4.0 * B * H * Tq * Tk * 64):
+        d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
+        check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
 
 
 def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0):
@@ -193,7 +237,8 @@ def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0
         setattr(d, f"{field}_st", st)
     d.delta = delta.data_ptr()
     d.dq_scale = dq_scale
-    check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
+    with _probe("attention", 10.0 * B * H * Tq * Tk * 64):  # algorithmic: five products (the two passes run seven)
+        check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
 
 
 def embed_fwd(labels, table, pe, out, B, S, D, start_id):
@@ -207,8 +252,9 @@ def embed_bwd(labels, dy, dtable, B, S, D, start_id):
 
 
 def xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale):
-    check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
-                                 grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
+    with _probe("xent", 3.0 * B * S * V * logits.element_size()):
+        check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
+                                     grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
 
 
 def sum_scale(x, out, n, scale):
@@ -216,8 +262,9 @@ def sum_scale(x, out, n, scale):
 
 
 def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0, mirror=None):
-    check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
-                              eps, step, eps_mode, weight_decay, gscale, ptr(mirror), stream()), "tmi_adam_step")
+    with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * n):
+        check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
+                                  eps, step, eps_mode, weight_decay, gscale, ptr(mirror), stream()), "tmi_adam_step")
 
 
 def adam_scalars(lr, beta1, beta2, step, eps_mode=0, weight_decay=0.0):
