@@ -217,6 +217,14 @@ class WhisperForConditionalGeneration(KernelBlocks):
         self._buf("dh1pad", (B, self.Tp1 + slack, d), **z)
         self._buf("u2", (B, self.T, d))
         self._buf("du2pad", (B, self.T + 1, d), **z)
+        # conv1's reduction length 3*n_mels (240) is not a multiple of the GEMM's 64-deep K tile: the bf16
+        # path multiplies against a copy of the kernel padded with zero rows, so the tile-aligned kernels
+        # apply; the extra A columns are the next frames of xp0 (finite, inside the slack) times zero
+        self.K1p = -(-3 * cfg.n_mels // 64) * 64
+        if self.precision == "bf16" and self.K1p != 3 * cfg.n_mels and self.K1p - 3 * cfg.n_mels <= slack * cfg.n_mels:
+            self._buf("w1pad", (self.K1p, d), **z)
+        else:
+            self.ws.pop("w1pad", None)
         R, Rd = B * self.T, B * S
         for side, L, rows in (("enc", cfg.encoder_layers, R), ("dec", cfg.decoder_layers, Rd)):
             for i in range(L):
@@ -333,9 +341,16 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # ---- encoder stem (W:329-339)
         xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
         ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
-        self._gemm_xw(xp0, "encoder.conv1.kernel", h1pad, self.T1, d, 3 * Cn, Cn, ldc=d, nbatch=B,
-                      a_sb=xp0.stride(0), c_sb=h1pad.stride(0), c_off=self.pl2 * d,
-                      bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
+        w1pad = ws.get("w1pad")
+        if w1pad is not None:
+            w1pad[:3 * Cn].copy_(self.W("encoder.conv1.kernel")[0])
+            ops.gemm(xp0, w1pad, h1pad, self.T1, d, self.K1p, Cn, 1, d, 1, ldc=d, nbatch=B,
+                     a_sb=xp0.stride(0), c_sb=h1pad.stride(0), c_off=self.pl2 * d,
+                     bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
+        else:
+            self._gemm_xw(xp0, "encoder.conv1.kernel", h1pad, self.T1, d, 3 * Cn, Cn, ldc=d, nbatch=B,
+                          a_sb=xp0.stride(0), c_sb=h1pad.stride(0), c_off=self.pl2 * d,
+                          bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
         w2, ld2 = self.W("encoder.conv2.kernel")
         x = ws["enc0.x_in"] if cfg.encoder_layers else ws["enc_x"]
         self._gemm_xw(h1pad, "encoder.conv2.kernel", x, T, d, 3 * d, 2 * d, ldc=d, nbatch=B, a_sb=h1pad.stride(0),
