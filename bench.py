@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 CLIP_SECONDS = 30.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0            # HBM3E peak (same guide; ~6.3 TB/s is what streams reach)
+GF_PER_SAMPLE_BY_SIZE = {"tiny": 141.3, "small": 449.1, "large": 8320.6}
 GF_PER_SAMPLE = 449.1           # fwd+bwd algorithmic GFLOP per 30 s sample, small-ref
 
 
@@ -234,16 +235,19 @@ def main():
     if rank == 0:
         gb = args.batch_size * world
         value = CLIP_SECONDS * gb * args.steps / dt
+        c = model.config
+        shape_note = f"{c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, {c.encoder_layers}+{c.decoder_layers} layers"
+        gf_sample = GF_PER_SAMPLE_BY_SIZE.get(args.model_type)
         out = {
-            "metric": "audio-seconds/sec/node (Whisper-small, 30 s clips)",
+            "metric": f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)",
             "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"whisper-{args.model_type}-ref (reference 'small': 768/12h/3072, 4+4 layers) "
+            "config": {"workload": f"whisper-{args.model_type}-ref (reference '{args.model_type}': {shape_note}) "
                                    f"train step, per-GPU batch {args.batch_size}, 30 s clips [80x3000], S=100",
                        "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
-                       "step_tflops": GF_PER_SAMPLE * gb * args.steps / dt / 1e3 if args.model_type == "small" else None},
+                       "step_tflops": gf_sample * gb * args.steps / dt / 1e3 if gf_sample else None},
         }
         if roof is not None:
             out["roofline"] = roof

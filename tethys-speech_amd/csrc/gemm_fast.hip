@@ -1213,14 +1213,15 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
         d.K >= 4096 && d.nbatch == 1 && 2 * d.M * d.N * 4 <= d.workspace_bytes)
       return launch_p8<TC, true, true>(d, stream);
   }
-  // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py): +20 % on long reductions; with a
-  // k-strided B and a short K its un-overlapped epilogue (one workgroup per CU) loses to the two
-  // co-resident 128x128 workgroups, so those stay where they were.
+  // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py, tools/gemm_rule_probe.py): +20 % on long
+  // reductions, ahead or level from K = 1024 (d_model 1024 / 1280 layers); with a k-strided B and K = 768
+  // its un-overlapped epilogue (one workgroup per CU) loses to the two co-resident 128x128 workgroups, so
+  // those stay where they were.
   if constexpr (!A_KS) {
     static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256 &&
-        (d.K >= 1536 || (!B_KS && light_epi)))
+        (d.K >= 1024 || (!B_KS && light_epi)))
       return launch_p8<TC, false, B_KS>(d, stream);
   }
   return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);

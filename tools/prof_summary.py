@@ -13,7 +13,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(tr)):
     n = r["Kernel_Name"]
     if "gemm" in n or "attn" in n:
-        key = (n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")[:44], int(r["Grid_Size_X"]) // 256, r["Grid_Size_Y"], r["Grid_Size_Z"])
+        key = (n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")[:44], int(r["Grid_Size_X"]) // max(1, int(r.get("Workgroup_Size_X") or 256)), r["Grid_Size_Y"], r["Grid_Size_Z"])
         agg[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("-- gemm/attn by grid (workgroups x, y, z)")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:30]:
