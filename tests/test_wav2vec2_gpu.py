@@ -308,8 +308,9 @@ def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
     rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
     if precision == "bf16":
         # the trajectory is chaotic once a quantiser code flips (the argmin is discontinuous and every update
-        # then differs): hold the first three steps to 3 %, the rest to a loose band (summation order inside
-        # the GroupNorm / LayerNorm kernels is enough to move step 4 by 15 %)
-        assert max(rel[:3]) <= 0.03 and max(rel) <= 0.35 and all(np.isfinite(got)), (rel, got, gold["losses"])
+        # then differs): hold the first two steps to 3 %, the rest to a loose band (the order of the fp32
+        # atomic adds inside the weight-gradient / GroupNorm / LayerNorm kernels varies from run to run and is
+        # enough to move step 3 by 3-4 % and step 4 by 15 %)
+        assert max(rel[:2]) <= 0.03 and max(rel) <= 0.35 and all(np.isfinite(got)), (rel, got, gold["losses"])
     else:
         assert max(rel) <= tol, (rel, got, gold["losses"])

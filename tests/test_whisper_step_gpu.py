@@ -98,6 +98,31 @@ def test_ten_step_loss_curve_fp32_small_dims(dev):
     assert got[-1] < got[0]
 
 
+def test_ragged_final_batches_bf16(dev):
+    """The reference's dataset has no drop_remainder (W:812): a pass over the pool ends in a short batch.
+    bf16 path, pool of 7 in batches of 3 (3, 3, 1, 3, 3, 1): the workspaces are re-laid-out on every change of
+    batch size and the losses must stay on the oracle's curve (bf16 tolerance 2e-2)."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import optim, dist, train
+    cfg_kw = small_cfg()
+    model, ocfg, params = build("bf16", cfg_kw, dev)
+    S, B, T_in = 12, 3, 47
+    feats, labels = O.create_dummy_pool(seed=9, n_mels=cfg_kw["n_mels"], seq_len=T_in, max_target_length=S, num_samples=7)
+    ref_losses, _ = O.train_steps(ocfg, params, feats, labels, B, 6, lr=1e-3)
+    opt = optim.Adam(learning_rate=1e-3)
+    strat = dist.DataParallelStrategy(0, 1)
+    it = O.batches(feats, labels, B)
+    got, sizes = [], []
+    for _ in range(6):
+        f, l = next(it)
+        sizes.append(len(f))
+        loss = train.distributed_train_step(strat, model, (torch.from_numpy(np.ascontiguousarray(f)).to(dev),
+                                                           torch.from_numpy(np.ascontiguousarray(l)).to(dev)), opt)
+        got.append(float(loss.item()))
+    assert sizes == [3, 3, 1, 3, 3, 1]
+    assert max(abs(a - b) for a, b in zip(got, ref_losses)) <= 2e-2, (got, ref_losses)
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
 def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
     """BASELINE config #1(b): Whisper-tiny (384/6h/1536/4+4), B=2, 10 steps, 30 s clips,
