@@ -40,7 +40,7 @@ GF_PER_SAMPLE_BY_SIZE = {"tiny": 141.3, "small": 449.1, "large": 8320.6}  # SURV
 GF_PER_SAMPLE = 449.1           # fwd+bwd algorithmic GFLOP per 30 s sample, small-ref
 
 
-def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
+def cpu_baseline(model_type, seq_len, sample_batch=2, max_steps=6, budget_s=14.0):
     import torch
     from oracle import whisper_oracle as O  # checker, timed as the CPU baseline only
     cores = os.cpu_count() or 1
@@ -52,12 +52,12 @@ def cpu_baseline(model_type, seq_len, sample_batch=2, steps=2):
     torch.set_num_threads(cores)
     cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
     params = O.init_params(cfg, seed=1234, dtype=torch.float32)
-    feats, labels = O.create_dummy_pool(seed=1234, seq_len=seq_len, num_samples=sample_batch * (steps + 1))
+    feats, labels = O.create_dummy_pool(seed=1234, seq_len=seq_len, num_samples=sample_batch * (max_steps + 1))
     tw = time.time()
     O.train_steps(cfg, params, feats, labels, sample_batch, 1)  # warm-up
     log(f"cpu baseline warm-up step: {time.time() - tw:.1f} s on {cores} threads")
-    if time.time() - tw > 20.0:
-        steps = 1
+    # bounded sample: as many timed steps as fit ~budget_s of CPU work (the warm-up step sizes them)
+    steps = max(1, min(max_steps, int(budget_s / max(time.time() - tw, 1e-3))))
     t0 = time.time()
     O.train_steps(cfg, params, feats[sample_batch:], labels[sample_batch:], sample_batch, steps)
     dt = time.time() - t0
