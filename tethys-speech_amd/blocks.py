@@ -73,6 +73,13 @@ class Arena:
                 base = name[:-len("qkv.bias")]
                 for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
                     out[f"{base}{n}.bias"] = t[j * d:(j + 1) * d]
+            elif name.endswith(".cross_kv.kernel") or name.endswith(".cross_kv.bias"):
+                # the k/v projections of EVERY decoder layer side by side: columns [(2 i + j) d, +d) belong
+                # to layer i's k_proj (j = 0) / v_proj (j = 1)
+                base, leaf = name.rsplit("cross_kv.", 1)
+                for i in range(t.shape[-1] // (2 * d)):
+                    for j, n in enumerate(("k_proj", "v_proj")):
+                        out[f"{base}layers.{i}.encoder_attn.{n}.{leaf}"] = t[..., (2 * i + j) * d:(2 * i + j + 1) * d]
             elif name.endswith(".kv.kernel"):
                 base = name[:-len("kv.kernel")]
                 for j, n in enumerate(("k_proj", "v_proj")):

@@ -1,0 +1,610 @@
+// Fused multi-head attention for gfx950, bf16 in / fp32 accumulate, head_dim 64.
+// Replaces speech_jobs/whisper_dist.py:147-171 (q·kᵀ, additive mask, softmax, probs·v, head
+// merge) and its gradient without materialising the [B,H,Tq,Tk] score tensor.
+//
+// One structure serves forward, the dQ pass and the dK/dV pass:
+//   - a wavefront OWNS 32 rows (queries in fwd/dQ, keys in dK/dV); the owner index sits on
+//     the MFMA lane, its 64-wide vectors live in registers as B operands;
+//   - the other ("streamed") index is walked in 64-row tiles that the workgroup (4 waves =
+//     128 owners) stages ONCE, global -> LDS by DMA (global_load_lds_dwordx4), double-buffered
+//     so the next tile is in flight under the current tile's MFMAs;
+//   - ONE natural [row][64 d] LDS image per tile serves both products: row fragments by
+//     ds_read_b128 for X[s][o] = sum_d T[s][d]·Own[o][d], and hardware-transposed fragments by
+//     ds_read_b64_tr_b16 for Yᵀ[d][o] += sum_s T[s][d]·X[s][o].  The 16-byte chunk swizzle
+//     phys = chunk ^ (((row >> 1) & 1) << 2 | ((row >> 2) & 3)) makes both read kinds
+//     bank-conflict-free; it is applied to the DMA's per-lane source address and on the reads;
+//   - X (scores / probabilities / dS) never leaves the accumulator registers: a 32x32 MFMA
+//     result has its column on the lane and its rows in the registers, so it is directly the
+//     B operand of the next MFMA that sums over its rows (k-order inside a 16-step permuted:
+//     element j of lane-half h is row 16s + 8(j>>2) + 4h + (j&3); the transposed reads fetch
+//     the other operand in that same order);
+//   - softmax statistics are per-lane scalars in fwd/dQ (query on the lane) and per-row
+//     constants from LDS in dK/dV.
+// The reference's decoder mask (W:416-418 + W:152-153) adds -1e9 in fp32 to keys j <= i;
+// a fully masked row therefore softmaxes to exactly uniform, which is why (m, 1/l) are kept
+// as two numbers instead of one log-sum-exp.
+//
+// Softmax arithmetic runs in the log2 domain: c2 = score_scale * log2(e) is folded into one
+// fma per element, p = exp2(fma(s, c2, -m)) is a single v_exp_f32, and the stored statistic m
+// is in log2 units (private to these three kernels).  The masked constant becomes -1e9*log2(e),
+// which still absorbs every score in fp32, so the uniform-row behaviour is unchanged.  Tiles
+// that need no masking (all of the encoder except its last key tile) take a branch-free path;
+// the forward rescales its accumulators only when some row's maximum grew by more than 2^8
+// (any m works as long as l and O were accumulated with the same one).
+// The VALU budget matters as much as the MFMAs here: a 32x32x16 MFMA occupies the SIMD for
+// 32 cycles, v_exp_f32 costs 8 issue cycles and every other vector op 4.
+#include "tmi_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int TROWS = 64;             // streamed rows per tile
+constexpr int IMG = TROWS * 128;      // bytes of one [64][64] bf16 image
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float MASKED2 = -1e9f * LOG2E;  // the reference's -1e9, in log2 units
+constexpr float LAZY = 8.f;             // forward: rescale only when a maximum grew by > 2^8
+
+// Make the compiler's own wait-count model see a register as already loaded.  Without this it
+// believes the pre-loop global loads are still in flight (the explicit waits below are asm, opaque
+// to it) and puts s_waitcnt vmcnt(0) at their first use INSIDE the tile loop, which drains the
+// freshly issued LDS-DMA of the next tile every iteration.
+#define PIN(v) asm volatile("" : "+v"(v))
+
+// LDS-DMA from inline asm (see gemm_fast.hip: keeps hipcc from draining it before LDS reads)
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  const unsigned dst = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds_wave_base);
+  const unsigned dst_u = __builtin_amdgcn_readfirstlane(dst);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(dst_u)
+               : "memory");
+}
+
+// stage rows [row0, row0+64) of a [T][.. 64 d ..] matrix (token stride st elements) into img
+__device__ __forceinline__ void stage_img(char* img, const bf16_t* base, int64_t st, int row0, int T, int wave, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = 2 * wave + i;
+    const int r = 8 * j + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    int gr = row0 + r;
+    gr = gr < T ? gr : T - 1;
+    glds16(base + (int64_t)gr * st + c * 8, img + j * 1024);
+  }
+}
+
+// Same staging with the per-lane part of the source address computed once: lp[i] points at the
+// lane's 16 bytes of row r_i of tile 0; full tiles add a wave-uniform offset.
+struct LaneSrc {
+  const bf16_t* lp[2];
+  const bf16_t* base;
+  int64_t st;
+  int T;
+};
+__device__ __forceinline__ LaneSrc lane_src(const bf16_t* base, int64_t st, int T, int wave, int lane) {
+  LaneSrc L;
+  L.base = base;
+  L.st = st;
+  L.T = T;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 8 * (2 * wave + i) + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    L.lp[i] = base + (int64_t)r * st + c * 8;
+  }
+  return L;
+}
+__device__ __forceinline__ void stage_tile(char* img, const LaneSrc& L, int row0, int wave, int lane) {
+  if (row0 + TROWS <= L.T) {
+    const int64_t off = (int64_t)row0 * L.st;  // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(L.lp[i] + off, img + (2 * wave + i) * 1024);
+  } else {
+    stage_img(img, L.base, L.st, row0, L.T, wave, lane);
+  }
+}
+
+// owner vectors: lane (c, h) holds Own[o][16kk + 8h .. +7], kk = 0..3
+__device__ __forceinline__ void load_owner(bf16x8 (&f)[4], const bf16_t* base, int64_t st, int o, int T, int h) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    if (o < T) {
+      f[kk] = *reinterpret_cast<const bf16x8*>(base + (int64_t)o * st + kk * 16 + h * 8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[kk][j] = (bf16_t)0.f;
+    }
+  }
+}
+
+// X[s][o] = sum_d T[rb + s][d] * Own[o][d], s = 0..31
+__device__ __forceinline__ f32x16 first_product(const char* img, int rb, const bf16x8 (&own)[4], int c, int h) {
+  f32x16 x;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) x[e] = 0.f;
+  const int row = rb + c;
+  const int sw = swz(row);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * kk + h) ^ sw) << 4));
+    x = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, own[kk], x, 0, 0, 0);
+  }
+  return x;
+}
+
+// Yt[blk][d][o] += sum_s T[rb + s][32 blk + d] * X[s][o]   (X = fp32 accumulator, s = 0..31)
+__device__ __forceinline__ void second_product(const char* img, int rb, const f32x16& x, f32x16 (&y)[2], int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int h = g >> 1, q = i >> 2, p = i & 3;
+#pragma unroll
+  for (int sI = 0; sI < 2; ++sI) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (bf16_t)x[8 * sI + j];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      bf16x4 part[2];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = rb + 16 * sI + 8 * half + 4 * h + q;
+        const int col = 32 * blk + 16 * (g & 1) + 4 * p;
+        const char* addr = img + row * 128 + ((((col >> 3) ^ swz(row))) << 4) + (col & 7) * 2;
+        part[half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)addr);
+      }
+      const bf16x8 a = __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
+      y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[blk], 0, 0, 0);
+    }
+  }
+}
+
+// write Yt[blk][d][o] * scale to out[o][d] (bf16), owner o on the lane
+__device__ __forceinline__ void store_owner(const f32x16 (&y)[2], bf16_t* base, int64_t st, int o, int T, int h,
+                                            float scale) {
+  if (o >= T) return;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = (bf16_t)(y[blk][4 * g + i] * scale);
+      *reinterpret_cast<bf16x4*>(base + (int64_t)o * st + 32 * blk + 8 * g + 4 * h) = v;
+    }
+  }
+}
+
+#define ZERO2(y)                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) y[i_][e_] = 0.f
+
+// ------------------------------------------------------------------ forward
+struct AttnP {
+  tmi_attn_desc d;
+  float dq_scale;
+  float sscale;  // scores = (q . k) * sscale
+  float c2;      // sscale * log2(e)
+};
+
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
+  const tmi_attn_desc& d = P.d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int Tq = (int)d.Tq, Tk = (int)d.Tk;
+  const bool causal = d.mask_mode == 1;
+  const float c2 = P.c2;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(d.q) + b * d.q_sb + head * HD;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(d.k) + b * d.k_sb + head * HD;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(d.v) + b * d.v_sb + head * HD;
+
+  bf16x8 qf[4];
+  load_owner(qf, qb, d.q_st, q, Tq, h);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) PIN(qf[kk]);
+  f32x16 o[2];
+  ZERO2(o);
+  float m = -INFINITY, l = 0.f;
+
+  const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
+  const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
+  const int ntiles = (Tk + TROWS - 1) / TROWS;
+  stage_tile(smem, Ks, 0, wave, lane);
+  stage_tile(smem + IMG, Vs, 0, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  // one tile; EDGE = needs masking (causal, or the ragged last key tile)
+  auto body = [&](int tile, auto edge_tag) {
+    constexpr bool edge = decltype(edge_tag)::value;
+    const char* Kimg = smem + cur * 2 * IMG;
+    const char* Vimg = Kimg + IMG;
+    if (tile + 1 < ntiles) {
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_tile(nx, Ks, (tile + 1) * TROWS, wave, lane);
+      stage_tile(nx + IMG, Vs, (tile + 1) * TROWS, wave, lane);
+    }
+    f32x16 s[2];
+    s[0] = first_product(Kimg, 0, qf, c, h);   // s[key][q], keys 0..31 of the tile
+    s[1] = first_product(Kimg, 32, qf, c, h);  // keys 32..63
+    const int key0 = tile * TROWS;
+    float rs = 0.f;
+    if constexpr (!edge) {
+      // branch-free tile: maximum over the raw products (c2 > 0), lazy rescale
+      float mx = max3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) mx = max3(mx, s[0][e], s[0][e + 1]);
+      mx = max3(mx, s[0][15], s[1][0]);
+#pragma unroll
+      for (int e = 1; e < 15; e += 2) mx = max3(mx, s[1][e], s[1][e + 1]);
+      mx = fmaxf(mx, s[1][15]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mc = mx * c2;
+      if (__ballot(mc > m + LAZY) != 0) {
+        const float mnew = fmaxf(m, mc);
+        const float alpha = ex2(m - mnew);
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        m = mnew;
+      }
+      const float nm = -m;
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = ex2(fmaf(s[rbk][e], c2, nm));
+          s[rbk][e] = pe;
+          rs += pe;
+        }
+      }
+    } else {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + 32 * rbk + acc_row(e, h);
+          float x = s[rbk][e] * c2;
+          if (causal && key <= q) x = x + MASKED2;
+          if (key >= Tk) x = -INFINITY;
+          s[rbk][e] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);  // finite: every tile holds at least one key < Tk
+      const float alpha = ex2(m - mnew);
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+      m = mnew;
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pe = ex2(s[rbk][e] - mnew);
+          s[rbk][e] = pe;
+          rs += pe;
+        }
+      }
+    }
+    l += rs;
+    second_product(Vimg, 0, s[0], o, lane);
+    second_product(Vimg, 32, s[1], o, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  };
+  const int nfast = causal ? 0 : Tk / TROWS;  // full, unmasked tiles first
+  int tile = 0;
+  for (; tile < nfast; ++tile) body(tile, std::false_type{});
+  for (; tile < ntiles; ++tile) body(tile, std::true_type{});
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  bf16_t* ob = reinterpret_cast<bf16_t*>(d.o) + b * d.o_sb + head * HD;
+  store_owner(o, ob, d.o_st, q, Tq, h, inv);
+  if (h == 0 && q < Tq) {
+    float* st = d.stats + ((b * d.H + head) * Tq + q) * 2;
+    st[0] = m;  // log2 units
+    st[1] = inv;
+  }
+}
+
+// ------------------------------------------------------------------ dQ pass (owner = query)
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
+  const tmi_attn_desc& d = P.d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int Tq = (int)d.Tq, Tk = (int)d.Tk;
+  const bool causal = d.mask_mode == 1;
+  const float c2 = P.c2;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(d.q) + b * d.q_sb + head * HD;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(d.k) + b * d.k_sb + head * HD;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(d.v) + b * d.v_sb + head * HD;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(d.o) + b * d.o_sb + head * HD;
+  const bf16_t* dob = reinterpret_cast<const bf16_t*>(d.d_o) + b * d.do_sb + head * HD;
+
+  bf16x8 qf[4], dof[4];
+  float delta = 0.f;
+  {
+    bf16x8 of[4];
+    load_owner(qf, qb, d.q_st, q, Tq, h);
+    load_owner(dof, dob, d.do_st, q, Tq, h);
+    load_owner(of, ob, d.o_st, q, Tq, h);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta += (float)dof[kk][j] * (float)of[kk][j];
+  }
+  delta += __shfl_xor(delta, 32, 64);
+  float m = 0.f, linv = 0.f;
+  if (q < Tq) {
+    const int64_t si = (b * d.H + head) * Tq + q;
+    m = d.stats[si * 2];
+    linv = d.stats[si * 2 + 1];
+    if (h == 0) d.delta[si] = delta;
+  }
+  PIN(m);
+  PIN(linv);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    PIN(qf[kk]);
+    PIN(dof[kk]);
+  }
+  // p = exp2(x - m) / l = exp2(x - M), M = m + log2(l): one number is enough wherever no row is
+  // fully masked (mask_mode 0); the masked mode keeps (m, 1/l) because there m = -1.44e9 absorbs log2(l)
+  const float nM = lg2(linv) - m;
+  f32x16 dq[2];
+  ZERO2(dq);
+
+  const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
+  const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
+  const int ntiles = (Tk + TROWS - 1) / TROWS;
+  stage_tile(smem, Ks, 0, wave, lane);
+  stage_tile(smem + IMG, Vs, 0, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  auto body = [&](int tile, auto edge_tag) {
+    constexpr bool edge = decltype(edge_tag)::value;
+    const char* Kimg = smem + cur * 2 * IMG;
+    const char* Vimg = Kimg + IMG;
+    if (tile + 1 < ntiles) {
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_tile(nx, Ks, (tile + 1) * TROWS, wave, lane);
+      stage_tile(nx + IMG, Vs, (tile + 1) * TROWS, wave, lane);
+    }
+    const int key0 = tile * TROWS;
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      f32x16 s = first_product(Kimg, 32 * rbk, qf, c, h);    // s[key][q]
+      f32x16 dp = first_product(Vimg, 32 * rbk, dof, c, h);  // dp[key][q]
+      if constexpr (!edge) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = ex2(fmaf(s[e], c2, nM)) * (dp[e] - delta);  // dS
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = key0 + 32 * rbk + acc_row(e, h);
+          float x = s[e] * c2;
+          if (causal && key <= q) x = x + MASKED2;
+          const float pe = (key < Tk) ? ex2(x - m) * linv : 0.f;
+          s[e] = pe * (dp[e] - delta);
+        }
+      }
+      second_product(Kimg, 32 * rbk, s, dq, lane);  // dQt[d][q] += sum_key K[key][d] dS[key][q]
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  };
+  const int nfast = causal ? 0 : Tk / TROWS;
+  int tile = 0;
+  for (; tile < nfast; ++tile) body(tile, std::false_type{});
+  for (; tile < ntiles; ++tile) body(tile, std::true_type{});
+  bf16_t* dqb = reinterpret_cast<bf16_t*>(d.dq) + b * d.dq_sb + head * HD;
+  store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale * P.sscale);
+}
+
+// ------------------------------------------------------------------ dK/dV pass (owner = key)
+constexpr int NCONST = 4;  // per streamed query row: m, 1/l, delta, -(m + log2 l)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][NCONST][64] floats
+  const tmi_attn_desc& d = P.d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, h = lane >> 5;
+  const int head = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int key = blockIdx.x * 128 + wave * 32 + c;
+  const int Tq = (int)d.Tq, Tk = (int)d.Tk;
+  const bool causal = d.mask_mode == 1;
+  const float c2 = P.c2;
+  const bf16_t* qb = reinterpret_cast<const bf16_t*>(d.q) + b * d.q_sb + head * HD;
+  const bf16_t* kb = reinterpret_cast<const bf16_t*>(d.k) + b * d.k_sb + head * HD;
+  const bf16_t* vb = reinterpret_cast<const bf16_t*>(d.v) + b * d.v_sb + head * HD;
+  const bf16_t* dob = reinterpret_cast<const bf16_t*>(d.d_o) + b * d.do_sb + head * HD;
+  const float* stats = d.stats + (b * d.H + head) * Tq * 2;
+  const float* deltas = d.delta + (b * d.H + head) * Tq;
+  float* rowc_base = reinterpret_cast<float*>(smem + 4 * IMG);
+
+  bf16x8 kf[4], vf[4];
+  load_owner(kf, kb, d.k_st, key, Tk, h);
+  load_owner(vf, vb, d.v_st, key, Tk, h);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    PIN(kf[kk]);
+    PIN(vf[kk]);
+  }
+  f32x16 dk[2], dv[2];
+  ZERO2(dk);
+  ZERO2(dv);
+
+  // per-tile row constants: thread t carries (which = t / 64, row = t % 64)
+  // (the raw loads are combined only when they are written to LDS at the end of the iteration, so
+  // that nothing waits on them while the next tile's DMA is in flight)
+  const int cwhich = threadIdx.x >> 6;
+  auto load_consts = [&](int row0, float& x0, float& x1) {
+    const int qi = row0 + (threadIdx.x & 63);
+    x0 = 0.f;
+    x1 = 1.f;
+    if (qi < Tq) {
+      x0 = cwhich == 2 ? deltas[qi] : stats[qi * 2];
+      x1 = stats[qi * 2 + 1];
+    }
+  };
+  auto make_const = [&](float x0, float x1) -> float {
+    return cwhich == 1 ? x1 : (cwhich == 3 ? lg2(x1) - x0 : x0);
+  };
+
+  const LaneSrc Qs = lane_src(qb, d.q_st, Tq, wave, lane);
+  const LaneSrc Os = lane_src(dob, d.do_st, Tq, wave, lane);
+  const int ntiles = (Tq + TROWS - 1) / TROWS;
+  stage_tile(smem, Qs, 0, wave, lane);
+  stage_tile(smem + IMG, Os, 0, wave, lane);
+  {
+    float x0, x1;
+    load_consts(0, x0, x1);
+    rowc_base[threadIdx.x] = make_const(x0, x1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  auto body = [&](int tile, auto edge_tag) {
+    constexpr bool edge = decltype(edge_tag)::value;
+    const char* Qimg = smem + cur * 2 * IMG;
+    const char* Oimg = Qimg + IMG;
+    const float* rowc = rowc_base + cur * (NCONST * 64);
+    float cn0 = 0.f, cn1 = 1.f;
+    const bool more = tile + 1 < ntiles;
+    if (more) {
+      char* nx = smem + (cur ^ 1) * 2 * IMG;
+      stage_tile(nx, Qs, (tile + 1) * TROWS, wave, lane);
+      stage_tile(nx + IMG, Os, (tile + 1) * TROWS, wave, lane);
+      load_consts((tile + 1) * TROWS, cn0, cn1);
+    }
+    const int q0 = tile * TROWS;
+#pragma unroll
+    for (int rbk = 0; rbk < 2; ++rbk) {
+      f32x16 s = first_product(Qimg, 32 * rbk, kf, c, h);   // s[q][key]
+      f32x16 dp = first_product(Oimg, 32 * rbk, vf, c, h);  // dp[q][key]
+      f32x16 ds;
+      if constexpr (!edge) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int r = 32 * rbk + 8 * g + 4 * h;
+          const f32x4 nM = *reinterpret_cast<const f32x4*>(rowc + 192 + r);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(rowc + 128 + r);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int e = 4 * g + i;
+            const float pe = ex2(fmaf(s[e], c2, nM[i]));
+            s[e] = pe;
+            ds[e] = pe * (dp[e] - dl[i]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = 32 * rbk + acc_row(e, h);
+          const int qi = q0 + r;
+          float x = s[e] * c2;
+          if (causal && key <= qi) x = x + MASKED2;
+          const float pe = (qi < Tq) ? ex2(x - rowc[r]) * rowc[64 + r] : 0.f;
+          s[e] = pe;
+          ds[e] = pe * (dp[e] - rowc[128 + r]);
+        }
+      }
+      second_product(Oimg, 32 * rbk, s, dv, lane);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
+      second_product(Qimg, 32 * rbk, ds, dk, lane);  // dKt[d][key] += sum_q Q[q][d] dS[q][key]
+    }
+    if (more) rowc_base[(cur ^ 1) * (NCONST * 64) + threadIdx.x] = make_const(cn0, cn1);
+    PIN(cn0);  // the compiler's wait for these two loads belongs here, on every path, not after the
+    PIN(cn1);  // next iteration's DMA issue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  };
+  const int nfast = causal ? 0 : Tq / TROWS;
+  int tile = 0;
+  for (; tile < nfast; ++tile) body(tile, std::false_type{});
+  for (; tile < ntiles; ++tile) body(tile, std::true_type{});
+  bf16_t* dkb = reinterpret_cast<bf16_t*>(d.dk) + b * d.dk_sb + head * HD;
+  bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
+  store_owner(dk, dkb, d.dk_st, key, Tk, h, P.sscale);
+  store_owner(dv, dvb, d.dv_st, key, Tk, h, 1.0f);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool ok_mat(const void* p, int64_t sb, int64_t st) { return p && al16(p) && sb % 8 == 0 && st % 8 == 0; }
+
+int check_common(const tmi_attn_desc& d) {
+  if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
+      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f)
+    return 0;
+  return ok_mat(d.q, d.q_sb, d.q_st) && ok_mat(d.k, d.k_sb, d.k_st) && ok_mat(d.v, d.v_sb, d.v_st) &&
+         ok_mat(d.o, d.o_sb, d.o_st);
+}
+
+}  // namespace
+
+extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
+  if (!dp || !check_common(*dp)) {
+    tmi_set_error("tmi_attn_fwd: bad argument (16-byte aligned bf16 operands, strides multiple of 8)");
+    return TMI_ERR_INVALID;
+  }
+  AttnP P;
+  P.d = *dp;
+  P.dq_scale = 1.f;
+  P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
+  P.c2 = P.sscale * LOG2E;
+  dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
+  return tmi_check_launch("tmi_attn_fwd");
+}
+
+extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
+  if (!dp || !check_common(*dp) || !ok_mat(dp->d_o, dp->do_sb, dp->do_st) || !ok_mat(dp->dq, dp->dq_sb, dp->dq_st) ||
+      !ok_mat(dp->dk, dp->dk_sb, dp->dk_st) || !ok_mat(dp->dv, dp->dv_sb, dp->dv_st) || !dp->delta) {
+    tmi_set_error("tmi_attn_bwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  AttnP P;
+  P.d = *dp;
+  P.dq_scale = dp->dq_scale;
+  P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
+  P.c2 = P.sscale * LOG2E;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 gq((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 4 * IMG, s, P);
+  int rc = tmi_check_launch("tmi_attn_bwd(dq)");
+  if (rc) return rc;
+  dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
+  return tmi_check_launch("tmi_attn_bwd(dkv)");
+}

@@ -1210,7 +1210,7 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if constexpr (A_KS && B_KS && sizeof(TC) == 4) {
     static const int no_p8w = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     if (!no_p8w && force < 0 && wgrad_like && d.workspace && p8_eligible(d, true, true) && d.M * d.N >= 768 * 2304 &&
-        d.K >= 4096 && d.nbatch == 1 && (2 * d.M * d.N * 4 <= d.workspace_bytes || big_tiles >= 192))  // (>= 192 tiles: no split, no slabs)
+        d.K >= 4096 && d.nbatch == 1 && 2 * d.M * d.N * 4 <= d.workspace_bytes)
       return launch_p8<TC, true, true>(d, stream);
   }
   // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py, tools/gemm_rule_probe.py): +20 % on long

@@ -1,0 +1,420 @@
+// LayerNorm forward / backward over the last axis (HBM-bound; one wavefront per row,
+// 16-byte loads, wavefront-shuffle reductions).  Replaces
+// tf.keras.layers.LayerNormalization(epsilon=1e-5) at speech_jobs/whisper_dist.py:214,216,
+// 245,249,253,322,392 and its gradient.
+// Algorithmic bytes: fwd 2*n*s (+8 B/row stats), bwd 3*n*s (+ dgamma/dbeta partials).
+#include "tmi_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int LN_MAX_C = 2048;
+
+// A lane holds NCH 16-byte chunks of its row: chunk j covers columns (j*64 + lane)*VEC .. +VEC.
+// NCH is a template parameter so that a 768-wide row costs 2 chunks of registers, not the 4 (bf16)
+// or 8 (fp32) a 2048-wide one needs: the kernels are HBM-bound and live on waves in flight.
+template <typename T, int NCH_>
+struct RowIO {
+  static constexpr int VEC = 16 / sizeof(T);
+  static constexpr int NCH = NCH_;
+  static constexpr int E = NCH * VEC;
+  __device__ static __forceinline__ void load_raw(const T* row, int C, int lane, u32x4 (&raw)[NCH]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c0 = (j * 64 + lane) * VEC;
+      if (c0 < C) raw[j] = *reinterpret_cast<const u32x4*>(row + c0);
+      else raw[j] = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  __device__ static __forceinline__ void unpack(const u32x4 (&raw)[NCH], float (&v)[E]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const T* e = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[j * VEC + i] = to_f32(e[i]);
+    }
+  }
+  __device__ static __forceinline__ void store(T* row, int C, int lane, const float (&v)[E]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c0 = (j * 64 + lane) * VEC;
+      if (c0 < C) {
+        alignas(16) T e[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) e[i] = from_f32<T>(v[j * VEC + i]);
+        *reinterpret_cast<u32x4*>(row + c0) = *reinterpret_cast<const u32x4*>(e);
+      }
+    }
+  }
+  __device__ static __forceinline__ void load_f32vec(const float* p, int C, int lane, float (&v)[E]) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c0 = (j * 64 + lane) * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) v[j * VEC + i] = (c0 < C) ? p[c0 + i] : 0.f;
+    }
+  }
+};
+
+// Each wave walks rows blockIdx*4 + wave, + gridDim*4, ... with the next row's 16-byte loads
+// issued before the current row is reduced.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int C, float eps) {
+  using IO = RowIO<T, NCH>;
+  constexpr int E = IO::E;
+  const int lane = threadIdx.x & 63;
+  const int64_t step = (int64_t)gridDim.x * 4;
+  int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float g[E], b[E];
+  IO::load_f32vec(gamma, C, lane, g);
+  IO::load_f32vec(beta, C, lane, b);
+  const float invC = 1.0f / (float)C;
+  u32x4 nxt[NCH];
+  IO::load_raw(x + row * C, C, lane, nxt);
+  for (; row < rows; row += step) {
+    float v[E];
+    IO::unpack(nxt, v);
+    if (row + step < rows) IO::load_raw(x + (row + step) * C, C, lane, nxt);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) s += v[i];
+    const float mu = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool in = ((j * 64 + lane) * IO::VEC) < C;
+#pragma unroll
+      for (int i = 0; i < IO::VEC; ++i) {
+        const float dlt = in ? v[j * IO::VEC + i] - mu : 0.f;
+        q += dlt * dlt;
+      }
+    }
+    const float var = wave_sum(q) * invC;
+    const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
+    IO::store(y + row * C, C, lane, v);
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+// dgamma/dbeta partials are folded over the block's 8 waves through LDS slabs (LDS float atomics
+// measured 3x slower) and added to the fp32 gradient (zeroed by the caller) with one global atomic
+// per column per block.  Every block adds
+// to the same 2*C addresses, and same-address atomics serialise in L2 (measured: ~10 us per 512
+// blocks at C = 768), so the grid is kept to about one block per CU and each block starts its
+// column walk at a different offset.
+constexpr int LNB_WAVES = 8;
+template <typename T, int NCH>
+__global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     T* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int64_t rows, int C,
+                                                     int accumulate_dx) {
+  using IO = RowIO<T, NCH>;
+  constexpr int E = IO::E;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [8 waves][2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[E], dg[E], db[E];
+  IO::load_f32vec(gamma, C, lane, g);
+#pragma unroll
+  for (int i = 0; i < E; ++i) dg[i] = db[i] = 0.f;
+  const float invC = 1.0f / (float)C;
+  const int64_t step = (int64_t)gridDim.x * LNB_WAVES;
+  int64_t row = (int64_t)blockIdx.x * LNB_WAVES + wave;
+  u32x4 nx[NCH], ndy[NCH], nold[NCH];
+  float nmu = 0.f, nrs = 0.f;
+  if (row < rows) {
+    IO::load_raw(x + row * C, C, lane, nx);
+    IO::load_raw(dy + row * C, C, lane, ndy);
+    if (accumulate_dx) IO::load_raw(dx + row * C, C, lane, nold);
+    nmu = mean[row];
+    nrs = rstd[row];
+  }
+  for (; row < rows; row += step) {
+    float xv[E], dv[E], old[E];
+    IO::unpack(nx, xv);
+    IO::unpack(ndy, dv);
+    if (accumulate_dx) IO::unpack(nold, old);
+    const float mu = nmu, rs = nrs;
+    const int64_t nr = row + step;
+    if (nr < rows) {
+      IO::load_raw(x + nr * C, C, lane, nx);
+      IO::load_raw(dy + nr * C, C, lane, ndy);
+      if (accumulate_dx) IO::load_raw(dx + nr * C, C, lane, nold);
+      nmu = mean[nr];
+      nrs = rstd[nr];
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const bool in = ((j * 64 + lane) * IO::VEC) < C;
+#pragma unroll
+      for (int i = 0; i < IO::VEC; ++i) {
+        const int e = j * IO::VEC + i;
+        const float xh = in ? (xv[e] - mu) * rs : 0.f;
+        const float gg = dv[e] * g[e];
+        xv[e] = xh;
+        s1 += gg;
+        s2 += gg * xh;
+        dg[e] += dv[e] * xh;
+        db[e] += dv[e];
+      }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float r = rs * (dv[e] * g[e] - s1 - xv[e] * s2);
+      if (accumulate_dx) r += old[e];
+      dv[e] = r;
+    }
+    IO::store(dx + row * C, C, lane, dv);
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c0 = (j * 64 + lane) * IO::VEC;
+    if (c0 < C) {
+#pragma unroll
+      for (int i = 0; i < IO::VEC; ++i) {
+        red[(wave * 2 + 0) * C + c0 + i] = dg[j * IO::VEC + i];
+        red[(wave * 2 + 1) * C + c0 + i] = db[j * IO::VEC + i];
+      }
+    }
+  }
+  __syncthreads();
+  const int start = (int)((blockIdx.x * 64u) % (unsigned)C);
+  for (int i = threadIdx.x; i < C; i += 64 * LNB_WAVES) {
+    int c = start + i;
+    c = c >= C ? c - C : c;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_WAVES; ++w) {
+      a += red[(w * 2 + 0) * C + c];
+      b += red[(w * 2 + 1) * C + c];
+    }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+// chunk count for a row of C elements: smallest instantiated NCH that covers it
+template <typename T>
+inline int ln_nch(int64_t C) {
+  const int vec = 16 / (int)sizeof(T);
+  const int need = (int)((C + 64 * vec - 1) / (64 * vec));
+  return need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 8;
+}
+template <typename T, typename F>
+inline void ln_dispatch(int64_t C, F&& f) {
+  switch (ln_nch<T>(C)) {
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    default: f(std::integral_constant<int, 8>{}); break;
+  }
+}
+
+// Column sums (bias gradients).  A block owns 64 * VEC columns and a strided set of rows; its 8 waves
+// keep four 16-byte row loads in flight each, fold through LDS and add to `out` with one atomic per
+// column.  All blocks of a column group hit the same addresses and same-address atomics serialise in
+// L2 (~20 ns each), so the grid is ~one block per CU rather than thousands of small ones.
+constexpr int CS_WAVES = 8;
+template <typename T>
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
+                                                               int64_t rows, int64_t N) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[CS_WAVES][64 * VEC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (c0 < N) {
+    const int64_t step = (int64_t)gridDim.y * CS_WAVES;
+    int64_t row = (int64_t)blockIdx.y * CS_WAVES + wave;
+    const T* p = dy + row * ld + c0;
+    for (; row + 3 * step < rows; row += 4 * step, p += 4 * step * ld) {
+      u32x4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const u32x4*>(p + u * step * ld);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const T* e = reinterpret_cast<const T*>(&raw[u]);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] += to_f32(e[i]);
+      }
+    }
+    for (; row < rows; row += step, p += step * ld) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+      const T* e = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += to_f32(e[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = acc[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 64 * VEC; c += 64 * CS_WAVES) {
+    const int64_t n = (int64_t)blockIdx.x * 64 * VEC + c;
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < CS_WAVES; ++w) a += red[w][c];
+    if (n < N) atomicAdd(out + n, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ u,
+                                                       T* __restrict__ dx, int64_t nvec, int64_t dy_sb, int64_t u_sb,
+                                                       int64_t dx_sb) {
+  constexpr int VEC = 16 / sizeof(T);
+  dy += (int64_t)blockIdx.y * dy_sb;  // batch (blockIdx.y) strides in elements, multiples of VEC
+  u += (int64_t)blockIdx.y * u_sb;
+  dx += (int64_t)blockIdx.y * dx_sb;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const u32x4 a = reinterpret_cast<const u32x4*>(dy)[i];
+    const u32x4 b = reinterpret_cast<const u32x4*>(u)[i];
+    const T* ea = reinterpret_cast<const T*>(&a);
+    const T* eb = reinterpret_cast<const T*>(&b);
+    alignas(16) T o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = from_f32<T>(to_f32(ea[j]) * gelu_grad_t<T>(to_f32(eb[j])));
+    reinterpret_cast<u32x4*>(dx)[i] = *reinterpret_cast<const u32x4*>(o);
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
+  const int vec = dtype == TMI_BF16 ? 8 : 4;
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || C > LN_MAX_C || C % vec ||
+      !al16(x) || !al16(y)) {
+    tmi_set_error("tmi_layernorm_fwd: bad argument (C must be a multiple of 16 bytes and <= 2048)");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // whole rows per wave, at most ~1024 blocks of 4 waves (measured best on MI355X: 11.4 us for [12000, 768] bf16)
+  static const int64_t cap_f = [] { const char* e = getenv("TMI_LN_FWD_BLOCKS"); return e ? atoll(e) : 1024ll; }();
+  const int64_t rpw = (rows + 4 * cap_f - 1) / (4 * cap_f);
+  dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+  if (dtype == TMI_BF16) {
+    ln_dispatch<bf16_t>(C, [&](auto nch) {
+      hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, decltype(nch)::value>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
+                         (bf16_t*)y, mean, rstd, rows, (int)C, eps);
+    });
+  } else if (dtype == TMI_F32) {
+    ln_dispatch<float>(C, [&](auto nch) {
+      hipLaunchKernelGGL((ln_fwd_kernel<float, decltype(nch)::value>), grid, dim3(256), 0, s, (const float*)x, gamma, beta,
+                         (float*)y, mean, rstd, rows, (int)C, eps);
+    });
+  } else {
+    return TMI_ERR_UNSUPPORTED;
+  }
+  return tmi_check_launch("tmi_layernorm_fwd");
+}
+
+extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                 int32_t accumulate_dx, int32_t dtype, void* stream) {
+  const int vec = dtype == TMI_BF16 ? 8 : 4;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
+      C % vec || !al16(x) || !al16(dy) || !al16(dx)) {
+    tmi_set_error("tmi_layernorm_bwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  static const int64_t cap_b = [] { const char* e = getenv("TMI_LN_BWD_BLOCKS"); return e ? atoll(e) : 256ll; }();
+  int64_t rpw = (rows + LNB_WAVES * cap_b - 1) / (LNB_WAVES * cap_b);
+  if (rpw < 2) rpw = 2;  // amortise the per-block dgamma/dbeta fold
+  const int64_t blocks = (rows + LNB_WAVES * rpw - 1) / (LNB_WAVES * rpw);
+  const size_t lds = (size_t)LNB_WAVES * 2 * C * sizeof(float);  // <= 128 KiB at C = 2048
+  if (dtype == TMI_BF16) {
+    ln_dispatch<bf16_t>(C, [&](auto nch) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<bf16_t, decltype(nch)::value>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
+      (void)attr;
+      hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
+                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, rows, (int)C,
+                         accumulate_dx);
+    });
+  } else if (dtype == TMI_F32) {
+    ln_dispatch<float>(C, [&](auto nch) {
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<float, decltype(nch)::value>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
+      (void)attr;
+      hipLaunchKernelGGL((ln_bwd_kernel<float, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
+                         (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, (int)C,
+                         accumulate_dx);
+    });
+  } else {
+    return TMI_ERR_UNSUPPORTED;
+  }
+  return tmi_check_launch("tmi_layernorm_bwd");
+}
+
+extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
+                          void* stream) {
+  const int vec = dtype == TMI_BF16 ? 8 : 4;
+  if (!dy || !out || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy)) {
+    tmi_set_error("tmi_colsum: bad argument (N and ld must be multiples of 16 bytes)");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t xb = (N + 64 * vec - 1) / (64 * vec);
+  static const int64_t cs_blocks = [] { const char* e = getenv("TMI_COLSUM_BLOCKS"); return e ? atoll(e) : 128ll; }();
+  int64_t yb = (rows + CS_WAVES * 4 - 1) / (CS_WAVES * 4);  // at least four rows per wave
+  const int64_t cap = (cs_blocks + xb - 1) / xb;
+  if (yb > cap) yb = cap;
+  if (yb < 1) yb = 1;
+  dim3 grid((unsigned)xb, (unsigned)yb);
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64 * CS_WAVES), 0, s, (const bf16_t*)dy, ld, out, rows, N);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64 * CS_WAVES), 0, s, (const float*)dy, ld, out, rows, N);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_colsum");
+}
+
+extern "C" int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
+                                    int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream) {
+  const int vec = dtype == TMI_BF16 ? 8 : 4;
+  if (!dy || !u || !dx || n <= 0 || nbatch <= 0 || nbatch > 65535 || n % vec || dy_sb % vec || u_sb % vec || dx_sb % vec ||
+      !al16(dy) || !al16(u) || !al16(dx)) {
+    tmi_set_error("tmi_gelu_bwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t nvec = n / vec;
+  int64_t blocks = (nvec + 255) / 256;
+  const int64_t cap = 4096 / nbatch > 0 ? 4096 / nbatch : 1;
+  if (blocks > cap) blocks = cap;
+  dim3 grid((unsigned)blocks, (unsigned)nbatch);
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)u, (bf16_t*)dx, nvec,
+                       dy_sb, u_sb, dx_sb);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)u, (float*)dx, nvec,
+                       dy_sb, u_sb, dx_sb);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_gelu_bwd");
+}
+
+extern "C" int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream) {
+  return tmi_gelu_bwd_batched(dy, u, dx, n, 1, 0, 0, 0, dtype, stream);
+}

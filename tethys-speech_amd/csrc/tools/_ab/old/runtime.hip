@@ -1,0 +1,23 @@
+// Host-side runtime glue of libtethys_mi.so: error slot and launch check.
+#include "tmi_common.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void tmi_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+int tmi_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return TMI_ERR_LAUNCH;
+  }
+  return TMI_OK;
+}
+
+extern "C" int tmi_abi_version(void) { return 9; }
+extern "C" const char* tmi_last_error(void) { return g_err; }

@@ -1,0 +1,299 @@
+// Row softmax (materialised-score fp32 attention path), shifted sparse cross-entropy with
+// fused gradient, decoder embedding gather / gradient.  All HBM-bound row kernels.
+// Reference call sites: speech_jobs/whisper_dist.py:147-167 (scores/mask/softmax),
+// :585-600 (shifted SparseCategoricalCrossentropy + reduce_mean), :405-408 + :559-563
+// (embedding of the right-shifted labels + positional encoding).
+#include "tmi_common.h"
+
+namespace {
+
+constexpr int SM_E = 32;  // Tk <= 64*32 = 2048
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ s, int64_t rows, int Tq, int Tk,
+                                                          int mask_mode) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* p = s + row * Tk;
+  const int qi = (int)(row % Tq);
+  float v[SM_E];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < SM_E; ++j) {
+    const int c = j * 64 + lane;
+    if (c < Tk) {
+      float x = p[c];
+      if (mask_mode == 1 && c <= qi) x = x + (-1e9f);  // fp32 add, as tf: score is absorbed
+      v[j] = x;
+      mx = fmaxf(mx, x);
+    } else {
+      v[j] = -INFINITY;
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < SM_E; ++j) {
+    const int c = j * 64 + lane;
+    const float e = (c < Tk) ? expf(v[j] - mx) : 0.f;
+    v[j] = e;
+    sum += e;
+  }
+  const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+  for (int j = 0; j < SM_E; ++j) {
+    const int c = j * 64 + lane;
+    if (c < Tk) p[c] = v[j] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                          int64_t rows, int Tk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = p + row * Tk;
+  float* dr = dp + row * Tk;
+  float pv[SM_E], dv[SM_E];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < SM_E; ++j) {
+    const int c = j * 64 + lane;
+    pv[j] = (c < Tk) ? pr[c] : 0.f;
+    dv[j] = (c < Tk) ? dr[c] : 0.f;
+    dot += pv[j] * dv[j];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int j = 0; j < SM_E; ++j) {
+    const int c = j * 64 + lane;
+    if (c < Tk) dr[c] = pv[j] * (dv[j] - dot);
+  }
+}
+
+// One 256-thread block per logits row.  Pass 1: online (max, sum); pass 2: write gradient.
+template <typename T>
+__global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
+                                                   float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / S), t = (int)(row % S);
+  T* lr = logits + row * ld;
+  const int64_t nch = ld / VEC;  // ld is a multiple of VEC (host-checked)
+  if (t >= S - 1) {  // unused row (W:586 drops the last position): zero gradient
+    alignas(16) T z[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) z[i] = from_f32<T>(0.f);
+    for (int64_t ch = threadIdx.x; ch < nch; ch += 256)
+      reinterpret_cast<u32x4*>(lr)[ch] = *reinterpret_cast<const u32x4*>(z);
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    return;
+  }
+  const int target = labels[(int64_t)b * S + t + 1];
+  float mx = -INFINITY, sum = 0.f;
+  for (int64_t ch = threadIdx.x; ch < nch; ch += 256) {
+    const u32x4 raw = reinterpret_cast<const u32x4*>(lr)[ch];
+    const T* e = reinterpret_cast<const T*>(&raw);
+    float lm = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (ch * VEC + i < V) lm = fmaxf(lm, to_f32(e[i]));
+    if (lm > mx) {
+      sum *= expf(mx - lm);  // exp(-inf) = 0 on first chunk
+      mx = lm;
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+      if (ch * VEC + i < V) sum += expf(to_f32(e[i]) - mx);
+  }
+  const float gmx = block_max_256(mx, red);
+  const float part = (mx == -INFINITY) ? 0.f : sum * expf(mx - gmx);
+  const float gsum = block_sum_256(part, red);
+  const float lse = gmx + logf(gsum);
+  const float inv = 1.0f / gsum;
+  if (threadIdx.x == 0) row_loss[row] = lse - to_f32(lr[target]);
+  __syncthreads();  // the target logit is read before anyone overwrites it
+  for (int64_t ch = threadIdx.x; ch < nch; ch += 256) {
+    const u32x4 raw = reinterpret_cast<const u32x4*>(lr)[ch];
+    const T* e = reinterpret_cast<const T*>(&raw);
+    alignas(16) T o[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const int64_t c = ch * VEC + i;
+      float g = 0.f;
+      if (c < V) {
+        g = expf(to_f32(e[i]) - gmx) * inv;
+        if (c == target) g -= 1.0f;
+        g *= grad_scale;
+      }
+      o[i] = from_f32<T>(g);
+    }
+    reinterpret_cast<u32x4*>(lr)[ch] = *reinterpret_cast<const u32x4*>(o);
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                        int64_t n, float scale) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+__device__ __forceinline__ int dec_id(const int32_t* labels, int64_t r, int S, int start_id) {
+  const int t = (int)(r % S);
+  return t == 0 ? start_id : labels[r - 1];  // labels[b, t-1]
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int32_t* __restrict__ labels, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, T* __restrict__ out, int S,
+                                                        int D, int start_id) {
+  const int64_t r = blockIdx.x;
+  const int t = (int)(r % S);
+  const int id = dec_id(labels, r, S, start_id);
+  const float* src = table + (int64_t)id * D;
+  const float* pr = pe + (int64_t)t * D;
+  for (int c = threadIdx.x; c < D; c += 256) out[r * D + c] = from_f32<T>(src[c] + pr[c]);
+}
+
+// Block r owns token id(r) iff no earlier row has the same id; it then sums dy over every
+// row with that id, in row order (deterministic).  The matching rows are compacted into an
+// LDS list first so the column sums run 8 independent loads deep (the pad token owns ~40 %
+// of all positions: a serial chain over them was the whole kernel's duration).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int32_t* __restrict__ labels, const T* __restrict__ dy,
+                                                        float* __restrict__ dtable, int n, int S, int D, int start_id) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* list = reinterpret_cast<int*>(smem);  // [n]
+  __shared__ int dup, cnt;
+  const int r = blockIdx.x;
+  const int id = dec_id(labels, r, S, start_id);
+  if (threadIdx.x == 0) { dup = 0; cnt = 0; }
+  __syncthreads();
+  for (int q = threadIdx.x; q < r; q += 256)
+    if (dec_id(labels, q, S, start_id) == id) dup = 1;
+  __syncthreads();
+  if (dup) return;
+  if (threadIdx.x < 64) {  // one wave builds the ordered list with ballot prefix sums
+    int base = 0;
+    for (int q0 = r; q0 < n; q0 += 64) {
+      const int q = q0 + threadIdx.x;
+      const bool hit = q < n && dec_id(labels, q, S, start_id) == id;
+      const unsigned long long m = __ballot(hit);
+      if (hit) list[base + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = q;
+      base += __popcll(m);
+    }
+    if (threadIdx.x == 0) cnt = base;
+  }
+  __syncthreads();
+  const int k = cnt;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s = 0.f;
+    int i = 0;
+    for (; i + 8 <= k; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = to_f32(dy[(int64_t)list[i + u] * D + c]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < k; ++i) s += to_f32(dy[(int64_t)list[i] * D + c]);
+    dtable[(int64_t)id * D + c] = s;
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tmi_softmax_fwd(float* s, int64_t rows, int64_t Tq, int64_t Tk, int32_t mask_mode, void* stream) {
+  if (!s || rows <= 0 || Tq <= 0 || Tk <= 0 || Tk > 64 * SM_E || (mask_mode != 0 && mask_mode != 1)) {
+    tmi_set_error("tmi_softmax_fwd: bad argument (Tk <= 2048)");
+    return TMI_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), s, rows, (int)Tq, (int)Tk, mask_mode);
+  return tmi_check_launch("tmi_softmax_fwd");
+}
+
+extern "C" int tmi_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t Tk, void* stream) {
+  if (!p || !dp || rows <= 0 || Tk <= 0 || Tk > 64 * SM_E) {
+    tmi_set_error("tmi_softmax_bwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p, dp, rows, (int)Tk);
+  return tmi_check_launch("tmi_softmax_bwd");
+}
+
+extern "C" int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
+                                int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream) {
+  const int vec = dtype == TMI_BF16 ? 8 : 4;
+  if (!logits || !labels || !row_loss || B <= 0 || S <= 1 || V <= 0 || ld < V || ld % vec || !al16(logits)) {
+    tmi_set_error("tmi_xent_fwd_bwd: bad argument (ld must be a multiple of 16 bytes, >= V)");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)(B * S));
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(xent_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V,
+                       grad_scale);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(xent_kernel<float>, grid, dim3(256), 0, s, (float*)logits, ld, labels, row_loss, (int)S, V,
+                       grad_scale);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_xent_fwd_bwd");
+}
+
+extern "C" int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stream) {
+  if (!x || !out || n <= 0) {
+    tmi_set_error("tmi_sum_scale: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, n,
+                     scale);
+  return tmi_check_launch("tmi_sum_scale");
+}
+
+extern "C" int tmi_embed_fwd(const int32_t* labels, const float* table, const float* pe, void* out, int64_t B,
+                             int64_t S, int64_t D, int32_t start_id, int32_t dtype, void* stream) {
+  if (!labels || !table || !pe || !out || B <= 0 || S <= 0 || D <= 0) {
+    tmi_set_error("tmi_embed_fwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)(B * S));
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(embed_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, labels, table, pe, (bf16_t*)out, (int)S,
+                       (int)D, start_id);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(embed_fwd_kernel<float>, grid, dim3(256), 0, s, labels, table, pe, (float*)out, (int)S,
+                       (int)D, start_id);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_embed_fwd");
+}
+
+extern "C" int tmi_embed_bwd(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
+                             int64_t D, int32_t start_id, int32_t dtype, void* stream) {
+  if (!labels || !dy || !dtable || B <= 0 || S <= 0 || D <= 0 || B * S > 16384) {
+    tmi_set_error("tmi_embed_bwd: bad argument (B*S <= 16384)");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int n = (int)(B * S);
+  const size_t lds = (size_t)n * sizeof(int);
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(n), dim3(256), lds, s, labels, (const bf16_t*)dy, dtable, n,
+                       (int)S, (int)D, start_id);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(n), dim3(256), lds, s, labels, (const float*)dy, dtable, n,
+                       (int)S, (int)D, start_id);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_embed_bwd");
+}

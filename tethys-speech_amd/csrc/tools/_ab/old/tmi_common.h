@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 kernels of libtethys_mi.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tethys_mi.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define TMI_WAVE 64
+
+// thread-local error slot, filled by launch helpers (host side)
+void tmi_set_error(const char* msg);
+int tmi_check_launch(const char* what);
+
+template <typename T> struct tmi_type;
+template <> struct tmi_type<float> { static constexpr int id = TMI_F32; };
+template <> struct tmi_type<bf16_t> { static constexpr int id = TMI_BF16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// exact-erf GELU (tf.keras.activations.gelu(approximate=False)) and its derivative
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// bf16-output variants: Abramowitz-Stegun 7.1.26 erf (|abs err| <= 1.5e-7, far below a bf16
+// ulp) — 1 rcp + 1 exp + 6 fma instead of erff's ~60 instructions, so the GELU epilogue of
+// the FFN GEMMs stays under the store time.  cdf and pdf share the one exponential.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);  // = exp(-x^2/2)
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float erf_abs = 1.0f - p * t * e;
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143267794f * e;
+}
+template <typename TC> __device__ __forceinline__ float gelu_fwd_t(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_fwd_t<bf16_t>(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return x * c;
+}
+template <typename TC> __device__ __forceinline__ float gelu_grad_t(float x) { return gelu_erf_grad(x); }
+template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
+  float c, p;
+  gelu_parts_fast(x, c, p);
+  return c + x * p;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); `red` is >= 4 floats of LDS
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}

@@ -127,6 +127,12 @@ class ParamArena(Arena):
             ffn(f"{p}.feed_forward")
         ln("encoder.layer_norm")
         spec.append(("decoder.embed_tokens.embeddings", (V, d)))
+        # W:122-123 projects the encoder output to k/v in every decoder layer: the L kernels are stored
+        # side by side as one [d, L*2d] matrix, so those projections (forward, dgrad, wgrad) are one GEMM
+        # each per step instead of L (reference variables = column slices, see Arena.ref_views)
+        if cfg.decoder_layers:
+            spec.extend([("decoder.cross_kv.kernel", (d, cfg.decoder_layers * 2 * d)),
+                         ("decoder.cross_kv.bias", (cfg.decoder_layers * 2 * d,))])
         for i in range(cfg.decoder_layers):
             p = f"decoder.layers.{i}"
             ln(f"{p}.self_attn_layer_norm")
@@ -134,7 +140,6 @@ class ParamArena(Arena):
                          (f"{p}.self_attn.out_proj.kernel", (d, d)), (f"{p}.self_attn.out_proj.bias", (d,))])
             ln(f"{p}.encoder_attn_layer_norm")
             spec.extend([(f"{p}.encoder_attn.q_proj.kernel", (d, d)), (f"{p}.encoder_attn.q_proj.bias", (d,)),
-                         (f"{p}.encoder_attn.kv.kernel", (d, 2 * d)), (f"{p}.encoder_attn.kv.bias", (2 * d,)),
                          (f"{p}.encoder_attn.out_proj.kernel", (d, d)), (f"{p}.encoder_attn.out_proj.bias", (d,))])
             ln(f"{p}.final_layer_norm")
             ffn(f"{p}.feed_forward")
@@ -244,7 +249,6 @@ class WhisperForConditionalGeneration(KernelBlocks):
                     self._buf(p + "x_mid2", (rows, d))
                     self._buf(p + "xn3", (rows, d))
                     self._buf(p + "qc", (rows, d))
-                    self._buf(p + "kvc", (R, 2 * d))
                     self._buf(p + "ctxc", (rows, d))
                     self._buf(p + "ln3.mean", (rows,), f32)
                     self._buf(p + "ln3.rstd", (rows,), f32)
@@ -270,7 +274,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._buf("lmh_dx32", (Rd, d), f32)  # split-K accumulator of the LM-head dgrad
         self._buf("dctx", (Rm, d))
         self._buf("dqkv", (Rm, 3 * d))
-        self._buf("dkvc", (R, 2 * d))
+        Lkv = max(1, cfg.decoder_layers) * 2 * d
+        self._buf("kvc_all", (R, Lkv))   # cross-attention k/v of every decoder layer, side by side
+        self._buf("dkv_all", (R, Lkv))
         self._buf("dU", (Rm, ff))
         He, Hd = cfg.encoder_attention_heads, cfg.decoder_attention_heads
         if self.precision == "bf16":
@@ -378,6 +384,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
         y = ws["dec0.x_in"] if cfg.decoder_layers else ws["dec_x"]
         ops.embed_fwd(labels, a.param("decoder.embed_tokens.embeddings"), self.pe_dec, y, B, S, d,
                       cfg.decoder_start_token_id)
+        kvc = ws["kvc_all"]
+        if cfg.decoder_layers:  # W:122-123 for all layers at once (see the parameter spec)
+            self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc)
         for i in range(cfg.decoder_layers):
             p, k = f"decoder.layers.{i}", f"dec{i}."
             x_in = ws[k + "x_in"]
@@ -390,10 +399,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
             # cross attention (W:278-290): k/v projections of the encoder output in every layer
             self._ln_fwd(ws[k + "x_mid"], p + ".encoder_attn_layer_norm", ws[k + "xn2"], k + "ln2")
             self._dense_fwd(ws[k + "xn2"], p + ".encoder_attn.q_proj.kernel", ws[k + "qc"], scale_cols=d, scale=scal_d)
-            self._dense_fwd(enc_out, p + ".encoder_attn.kv.kernel", ws[k + "kvc"])
-            kvc = ws[k + "kvc"]
-            self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0), (kvc, 0), (kvc, d),
-                           ws[k + "ctxc"], B, Hd, S, T, 0)
+            self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
+                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], B, Hd, S, T, 0)
             self._dense_fwd(ws[k + "ctxc"], p + ".encoder_attn.out_proj.kernel", ws[k + "x_mid2"],
                             resid=ws[k + "x_mid"], r_ld=d)
             self._ln_fwd(ws[k + "x_mid2"], p + ".final_layer_norm", ws[k + "xn3"], k + "ln3")
@@ -429,8 +436,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
         ready("decoder.layer_norm.gamma")
 
-        d_enc = ws["d_enc_out"]
-        first_cross = True
+        d_enc, dkv = ws["d_enc_out"], ws["dkv_all"]
         for i in reversed(range(cfg.decoder_layers)):
             p, k = f"decoder.layers.{i}", f"dec{i}."
             Rd = B * S
@@ -441,13 +447,10 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True)
             # cross attention
             self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctx)
-            kvc, dkvc, dqc = ws[k + "kvc"], ws["dkvc"], ws["dtmp"][:Rd]
-            self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0), (kvc, 0), (kvc, d),
-                           ws[k + "ctxc"], dctx, (dqc, 0), (dkvc, 0), (dkvc, d), B, Hd, S, T, 0)
-            # (moving this dgrad to the weight-gradient stream as well — d_enc is only consumed when the
-            # encoder's backward starts — measured slower: 9.65 vs 9.50 ms/step; the side stream is then the longer one)
-            self._dense_bwd(enc_out, dkvc, p + ".encoder_attn.kv.kernel", d_enc, accumulate_dx=not first_cross)
-            first_cross = False
+            dqc = ws["dtmp"][:Rd]
+            self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
+                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctx, (dqc, 0),
+                           (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0)
             dxn2 = ws["dctx"][:Rd]
             self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
             self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True)
@@ -459,6 +462,11 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
             ready(p + ".self_attn_layer_norm.gamma")
+        if cfg.decoder_layers:
+            # every layer's dk / dv is in place: one weight gradient, one bias gradient and one dgrad
+            # (K = L*2d) for the cross-attention k/v projections of all layers
+            self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
+            ready("decoder.cross_kv.kernel")
         ops.embed_bwd(labels, dres, a.grad("decoder.embed_tokens.embeddings"), B, S, d, cfg.decoder_start_token_id)
         ready("decoder.embed_tokens.embeddings")
 
