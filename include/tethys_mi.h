@@ -113,6 +113,14 @@ int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N,
 int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream);
 /* The same over nbatch spans of n elements whose starts are dy_sb / u_sb / dx_sb elements apart (one
  * launch for the per-sample spans of a padded buffer). */
+/* Dropout (tf.keras.layers.Dropout in training, W:205 / W:342 / W:411) over a [rows, cols] tensor, cols even:
+ *   out[r,c] = (resid ? resid[r,c] : 0) + (keep(seed, r*cols + c) ? in[r,c] * 65536/(65536-thr) : 0),
+ * thr = round(p * 65536): element e of the counter pair e>>1 is dropped when its 16-bit draw (low / high half of one
+ * 32-bit hash of (seed, e>>1)) is below thr.  Nothing is stored: the backward applies the same call (same seed) to the
+ * incoming gradient.  TF's RNG stream cannot be reproduced, so the mask differs from the reference's; the oracle
+ * restates this generator (oracle/dropout.py).  out may alias in. */
+int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
+                int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream);
 int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
                          int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream);
 
@@ -152,6 +160,11 @@ typedef struct tmi_attn_desc {
   float* delta;
   float dq_scale;              /* dq is multiplied by this on store (chain rule of W:141) */
   float score_scale;           /* scores = (q . k) * score_scale (V:349 divides AFTER q.k^T); 0 means 1 */
+  /* Dropout on the attention probabilities (W:160), training mode: 0 <= dropout_p < 1, 0 = off.  The keep
+   * mask is a function of (dropout_seed, b, head, q, k), regenerated by the backward kernels (see tmi_dropout);
+   * the row sums that normalise the probabilities are taken before dropping, as tf.nn.softmax -> Dropout does. */
+  float dropout_p;
+  uint64_t dropout_seed;
 } tmi_attn_desc;
 int tmi_attn_fwd(const tmi_attn_desc* d, void* stream);
 int tmi_attn_bwd(const tmi_attn_desc* d, void* stream);

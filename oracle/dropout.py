@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE (checker only): numpy restatement of the counter-based dropout generator of
+tethys-speech_amd/csrc/tmi_common.h (tmi_mix32 / tmi_pair_hash / tmi_stream_key / tmi_keep).
+
+The reference applies tf.keras.layers.Dropout in training (speech_jobs/whisper_dist.py:160, 205, 342, 411);
+TensorFlow's RNG stream cannot be reproduced, so the masks below are this build's own and parity with
+dropout enabled is defined against THIS generator: the same integer arithmetic on the host."""
+import numpy as np
+
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def _u32(x):
+    return np.asarray(x, dtype=np.uint64) & M32
+
+
+def mix32(x):
+    x = _u32(x)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def pair_hash(pid, key):
+    h = ((_u32(pid) ^ _u32(key)) * np.uint64(0x9E3779B1)) & M32
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & M32
+    return h
+
+
+def stream_key(seed, stream_id):
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    lo, hi = seed & 0xFFFFFFFF, seed >> 32
+    return mix32(np.uint64(lo) ^ mix32((np.uint64(hi) + _u32(stream_id)) & M32))
+
+
+def drop_thr(p):
+    return int(np.float32(p) * np.float32(65536.0) + np.float32(0.5))
+
+
+def keep_scale(p):
+    thr = drop_thr(p)
+    return float(np.float32(65536.0) / np.float32(65536 - thr))
+
+
+def keep_counter(key, idx, thr):
+    """keep decision of flat counters ``idx`` (uint64 array) in the stream with key ``key``."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = pair_hash((idx >> np.uint64(1)) & M32, key)
+    r = np.where(idx & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return r >= np.uint64(thr)
+
+
+def keep_flat(seed, rows, cols, p):
+    """[rows, cols] bool mask of tmi_dropout (cols even): counter = r * cols + c, stream 0."""
+    idx = np.arange(rows * cols, dtype=np.uint64).reshape(rows, cols)
+    return keep_counter(stream_key(seed, 0), idx, drop_thr(p))
+
+
+def keep_attention(seed, B, H, Tq, Tk, p):
+    """[B, H, Tq, Tk] bool mask of the attention kernels: stream b*H + head, counter q * 2*ceil(Tk/2) + k."""
+    kp = (Tk + 1) // 2
+    q = np.arange(Tq, dtype=np.uint64)[:, None]
+    k = np.arange(Tk, dtype=np.uint64)[None, :]
+    pid = (q * np.uint64(kp) + (k >> np.uint64(1))) & M32
+    out = np.empty((B, H, Tq, Tk), dtype=bool)
+    thr = np.uint64(drop_thr(p))
+    for b in range(B):
+        for h in range(H):
+            hh = pair_hash(pid, stream_key(seed, b * H + h))
+            r = np.where(k & np.uint64(1), hh >> np.uint64(16), hh & np.uint64(0xFFFF))
+            out[b, h] = r >= thr
+    return out

@@ -265,7 +265,7 @@ def test_softmax(dev, Tq, Tk, mask):
 
 
 # ----------------------------------------------------------------------------- attention
-def _attn_ref(q, k, v, mask_mode):
+def _attn_ref(q, k, v, mask_mode, keep=None, keep_scale=1.0):
     """fp64 reference of W:147-167 on [B,H,T,hd] inputs (q pre-scaled)."""
     s = q @ k.transpose(-1, -2)
     if mask_mode:
@@ -274,12 +274,16 @@ def _attn_ref(q, k, v, mask_mode):
         s32 = s.float() + add
         s = torch.where(add != 0, s + (s32.double() - s).detach(), s)
     p = torch.softmax(s, -1)
+    if keep is not None:  # tf.keras.layers.Dropout on the probabilities (W:160) with an explicit mask
+        p = p * keep * keep_scale
     return p @ v
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,mask", [(2, 3, 100, 100, 1), (1, 2, 200, 333, 0), (2, 2, 100, 1500, 0),
-                                            (1, 1, 31, 31, 1), (1, 12, 1500, 1500, 0)])
-def test_flash_attention(dev, B, H, Tq, Tk, mask):
+@pytest.mark.parametrize("B,H,Tq,Tk,mask,drop", [(2, 3, 100, 100, 1, 0.0), (1, 2, 200, 333, 0, 0.0), (2, 2, 100, 1500, 0, 0.0),
+                                                 (1, 1, 31, 31, 1, 0.0), (1, 12, 1500, 1500, 0, 0.0),
+                                                 (2, 3, 100, 100, 1, 0.1), (1, 2, 200, 333, 0, 0.1), (2, 2, 100, 1500, 0, 0.25),
+                                                 (1, 4, 1500, 1500, 0, 0.1)])
+def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     ops = _ops()
     D = H * 64
     bf = torch.bfloat16
@@ -289,14 +293,22 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask):
     v = rnd((B, Tk, D), bf, dev, 52)
     o = torch.empty((B, Tq, D), dtype=bf, device=dev)
     stats = torch.empty((B, H, Tq, 2), dtype=torch.float32, device=dev)
-    ops.attn_fwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats, B, H, Tq, Tk, mask)
+    seed = 0x1234ABCD5678 + Tq
+    ops.attn_fwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats, B, H, Tq, Tk, mask,
+                 dropout_p=drop, dropout_seed=seed)
     torch.cuda.synchronize()
+    keep, ks = None, 1.0
+    if drop > 0:  # the generator restated on the host: the kernels must drop exactly these probabilities
+        from oracle import dropout as DO
+        keep = torch.from_numpy(DO.keep_attention(seed, B, H, Tq, Tk, drop)).double()
+        ks = DO.keep_scale(drop)
+        assert abs(float(keep.mean()) - (1.0 - drop)) < 0.01
 
     def heads(t, T):
         return t.double().cpu().reshape(B, T, H, 64).permute(0, 2, 1, 3)
 
     qr, kr, vr = heads(q, Tq).requires_grad_(True), heads(k, Tk).requires_grad_(True), heads(v, Tk).requires_grad_(True)
-    outr = _attn_ref(qr, kr, vr, mask)
+    outr = _attn_ref(qr, kr, vr, mask, keep, ks)
     ref_o = outr.permute(0, 2, 1, 3).reshape(B, Tq, D)
     assert rel_err(o, ref_o) <= 2e-2
     do = rnd((B, Tq, D), bf, dev, 53)
@@ -305,7 +317,7 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask):
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=dev)
     ops.attn_bwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats,
                  (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D), (dv, 0, Tk * D, D), delta,
-                 B, H, Tq, Tk, mask, dq_scale=0.5)
+                 B, H, Tq, Tk, mask, dq_scale=0.5, dropout_p=drop, dropout_seed=seed)
     torch.cuda.synchronize()
 
     def merge(t, T):
@@ -314,6 +326,31 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask):
     assert rel_err(dv, merge(vr.grad, Tk)) <= 3e-2
     assert rel_err(dk, merge(kr.grad, Tk)) <= 3e-2
     assert rel_err(dq, 0.5 * merge(qr.grad, Tq)) <= 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_resid", [False, True])
+def test_dropout_kernel_matches_host_generator(dev, dtype, with_resid):
+    """tmi_dropout against the generator restated in oracle/dropout.py: same mask bit for bit, kept values
+    scaled by 65536/(65536-thr), residual added in fp32 (W:205 / W:342 / W:411 sites and their backward)."""
+    from oracle import dropout as DO
+    ops = _ops()
+    rows, cols, p, seed = 301, 768, 0.1, 0xFEEDFACE12345
+    x = rnd((rows, cols + 8), dtype, dev, 90)[:, :cols]      # row stride != cols
+    resid = rnd((rows, cols), dtype, dev, 91) if with_resid else None
+    out = torch.empty((rows, cols), dtype=dtype, device=dev)
+    ops.dropout(x, out, rows, cols, p, seed, resid=resid)
+    keep = torch.from_numpy(DO.keep_flat(seed, rows, cols, p)).to(dev)
+    ref = torch.where(keep, x.float() * DO.keep_scale(p), torch.zeros((), device=dev))
+    if with_resid:
+        ref = ref + resid.float()
+    assert torch.equal(out, ref.to(dtype))
+    assert abs(float(keep.float().mean()) - 0.9) < 5e-3
+    # in place, and the backward use: the same call on a gradient reproduces the mask
+    g = rnd((rows, cols), dtype, dev, 92)
+    g2 = g.clone()
+    ops.dropout(g2, g2, rows, cols, p, seed)
+    assert torch.equal(g2, torch.where(keep, g.float() * DO.keep_scale(p), torch.zeros((), device=dev)).to(dtype))
 
 
 # ----------------------------------------------------------------------------- embed / xent / adam / misc

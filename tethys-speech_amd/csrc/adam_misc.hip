@@ -122,6 +122,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// out[r, c] = (resid ? resid[r, c] : 0) + (keep(r * cols + c) ? in[r, c] * scale : 0)      (Dropout, see tmi_common.h)
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ in, int64_t ld_in, const T* __restrict__ resid,
+                                                      int64_t ld_res, T* __restrict__ out, int64_t ld_out, int64_t rows,
+                                                      int64_t cols, uint32_t key, uint32_t thr, float scale) {
+  const int64_t pairs_per_row = cols >> 1;  // cols is even (host-checked): a counter pair never straddles rows
+  const int64_t total = rows * pairs_per_row;
+  for (int64_t pid = (int64_t)blockIdx.x * 256 + threadIdx.x; pid < total; pid += (int64_t)gridDim.x * 256) {
+    const int64_t r = pid / pairs_per_row, c = (pid - r * pairs_per_row) * 2;
+    const uint32_t h = tmi_pair_hash((uint32_t)pid, key);
+    const bool k0 = (h & 0xffffu) >= thr, k1 = (h >> 16) >= thr;
+    float a0 = k0 ? to_f32(in[r * ld_in + c]) * scale : 0.f;
+    float a1 = k1 ? to_f32(in[r * ld_in + c + 1]) * scale : 0.f;
+    if (resid) {
+      a0 += to_f32(resid[r * ld_res + c]);
+      a1 += to_f32(resid[r * ld_res + c + 1]);
+    }
+    out[r * ld_out + c] = from_f32<T>(a0);
+    out[r * ld_out + c + 1] = from_f32<T>(a1);
+  }
+}
+
 }  // namespace
 
 extern "C" int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
@@ -302,4 +324,30 @@ extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, cons
                      reinterpret_cast<hipStream_t>(stream), spec, ld_spec, mel, out, frames, (int)n_bins, (int)n_mels, eps,
                      (int)channels_first, ld_out);
   return tmi_check_launch("tmi_logmel_from_spectrum");
+}
+
+// Dropout over a [rows, cols] tensor (cols even), optionally added to a residual: the forward of W:205 / W:342 /
+// W:411 and, applied to the incoming gradient with the same seed, their backward.  In-place (out == in) is fine.
+extern "C" int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
+                           int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0 || (cols & 1) || ld_in < cols || ld_out < cols || (resid && ld_res < cols) ||
+      !(p >= 0.f && p < 1.f)) {
+    tmi_set_error("tmi_dropout: bad argument (cols must be even, 0 <= p < 1)");
+    return TMI_ERR_INVALID;
+  }
+  const uint32_t thr = tmi_drop_thr(p);
+  const float scale = tmi_keep_scale(thr);
+  const uint32_t key = tmi_stream_key(seed, 0u);
+  const int64_t pairs = rows * (cols >> 1);
+  const unsigned blocks = (unsigned)((pairs + 255) / 256 < 2048 ? (pairs + 255) / 256 : 2048);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == TMI_BF16)
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(in), ld_in,
+                       reinterpret_cast<const bf16_t*>(resid), ld_res, reinterpret_cast<bf16_t*>(out), ld_out, rows, cols, key, thr, scale);
+  else if (dtype == TMI_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(in), ld_in,
+                       reinterpret_cast<const float*>(resid), ld_res, reinterpret_cast<float*>(out), ld_out, rows, cols, key, thr, scale);
+  else
+    return TMI_ERR_UNSUPPORTED;
+  return tmi_check_launch("tmi_dropout");
 }

@@ -195,9 +195,15 @@ struct AttnP {
   float dq_scale;
   float sscale;  // scores = (q . k) * sscale
   float c2;      // sscale * log2(e)
+  // dropout on the probabilities (W:160): thr == 0 is off; see tmi_common.h for the generator.  The counter of
+  // element (q, k) in stream b*H + head is q * ceil(Tk/2) * 2 + k: pairs run along k.
+  uint32_t drop_thr;
+  float keep_scale;
+  uint32_t seed_lo, seed_hi;
 };
 
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
   const int lane = threadIdx.x & 63;
@@ -220,6 +226,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
   f32x16 o[2];
   ZERO2(o);
   float m = -INFINITY, l = 0.f;
+  const uint32_t drop_thr = P.drop_thr;
+  const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
+  const uint32_t qpid = (uint32_t)q * (uint32_t)((Tk + 1) >> 1);
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
@@ -309,6 +318,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
       }
     }
     l += rs;
+    if constexpr (DROP) {  // zero the dropped probabilities; the kept ones are rescaled on the final store
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t hh = tmi_pair_hash(qpid + (uint32_t)((key0 + 32 * rbk + 8 * g + 4 * h) >> 1) + j, skey);
+            if ((hh & 0xffffu) < drop_thr) s[rbk][4 * g + 2 * j] = 0.f;
+            if ((hh >> 16) < drop_thr) s[rbk][4 * g + 2 * j + 1] = 0.f;
+          }
+    }
     second_product(Vimg, 0, s[0], o, lane);
     second_product(Vimg, 32, s[1], o, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
   bf16_t* ob = reinterpret_cast<bf16_t*>(d.o) + b * d.o_sb + head * HD;
-  store_owner(o, ob, d.o_st, q, Tq, h, inv);
+  store_owner(o, ob, d.o_st, q, Tq, h, DROP ? inv * P.keep_scale : inv);
   if (h == 0 && q < Tq) {
     float* st = d.stats + ((b * d.H + head) * Tq + q) * 2;
     st[0] = m;  // log2 units
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const AttnP P) {
 }
 
 // ------------------------------------------------------------------ dQ pass (owner = query)
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
   const int lane = threadIdx.x & 63;
@@ -381,6 +403,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
   const float nM = lg2(linv) - m;
   f32x16 dq[2];
   ZERO2(dq);
+  const uint32_t drop_thr = P.drop_thr;
+  const float keep_scale = P.keep_scale;
+  const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
+  const uint32_t qpid = (uint32_t)q * (uint32_t)((Tk + 1) >> 1);
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
@@ -404,9 +430,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
     for (int rbk = 0; rbk < 2; ++rbk) {
       f32x16 s = first_product(Kimg, 32 * rbk, qf, c, h);    // s[key][q]
       f32x16 dp = first_product(Vimg, 32 * rbk, dof, c, h);  // dp[key][q]
+      // with dropout, d(p) = mask / keep * d(dropped p): one hash per pair of keys
+      auto dpm = [&](int e, uint32_t hh) -> float {
+        if constexpr (DROP) return ((e & 1) ? (hh >> 16) : (hh & 0xffffu)) < drop_thr ? 0.f : dp[e] * keep_scale;
+        else return dp[e];
+      };
+      auto pair_draw = [&](int e) -> uint32_t {  // e even
+        if constexpr (DROP) return tmi_pair_hash(qpid + (uint32_t)((key0 + 32 * rbk + 8 * (e >> 2) + 4 * h) >> 1) + ((e >> 1) & 1), skey);
+        else return 0u;
+      };
       if constexpr (!edge) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = ex2(fmaf(s[e], c2, nM)) * (dp[e] - delta);  // dS
+        for (int e = 0; e < 16; e += 2) {
+          const uint32_t hh = pair_draw(e);
+          s[e] = ex2(fmaf(s[e], c2, nM)) * (dpm(e, hh) - delta);  // dS
+          s[e + 1] = ex2(fmaf(s[e + 1], c2, nM)) * (dpm(e + 1, hh) - delta);
+        }
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -414,7 +453,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
           float x = s[e] * c2;
           if (causal && key <= q) x = x + MASKED2;
           const float pe = (key < Tk) ? ex2(x - m) * linv : 0.f;
-          s[e] = pe * (dp[e] - delta);
+          s[e] = pe * (dpm(e, pair_draw(e & ~1)) - delta);
         }
       }
       second_product(Kimg, 32 * rbk, s, dq, lane);  // dQt[d][q] += sum_key K[key][d] dS[key][q]
@@ -433,7 +472,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnP P) {
 
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
 constexpr int NCONST = 4;  // per streamed query row: m, 1/l, delta, -(m + log2 l)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][NCONST][64] floats
   const tmi_attn_desc& d = P.d;
   const int lane = threadIdx.x & 63;
@@ -464,6 +504,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
   f32x16 dk[2], dv[2];
   ZERO2(dk);
   ZERO2(dv);
+  const uint32_t drop_thr = P.drop_thr;
+  const float keep_scale = P.keep_scale;
+  const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
+  const uint32_t kp = (uint32_t)((Tk + 1) >> 1), khalf = (uint32_t)key >> 1, ksh = ((uint32_t)key & 1u) * 16u;
+  auto keep_at = [&](uint32_t qi) -> bool {  // this lane's key against query row qi
+    const uint32_t hh = tmi_pair_hash(qi * kp + khalf, skey);
+    return ((hh >> ksh) & 0xffffu) >= drop_thr;
+  };
 
   // per-tile row constants: thread t carries (which = t / 64, row = t % 64)
   // (the raw loads are combined only when they are written to LDS at the end of the iteration, so
@@ -524,8 +572,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * g + i;
             const float pe = ex2(fmaf(s[e], c2, nM[i]));
-            s[e] = pe;
-            ds[e] = pe * (dp[e] - dl[i]);
+            if constexpr (DROP) {  // dV sees the dropped probabilities, dS the masked dP: ds = p * (mask/keep * dp - delta)
+              const bool keep = keep_at((uint32_t)(q0 + r + i));
+              s[e] = keep ? pe : 0.f;
+              ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - dl[i]);
+            } else {
+              s[e] = pe;
+              ds[e] = pe * (dp[e] - dl[i]);
+            }
           }
         }
       } else {
@@ -536,8 +590,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
           float x = s[e] * c2;
           if (causal && key <= qi) x = x + MASKED2;
           const float pe = (qi < Tq) ? ex2(x - rowc[r]) * rowc[64 + r] : 0.f;
-          s[e] = pe;
-          ds[e] = pe * (dp[e] - rowc[128 + r]);
+          if constexpr (DROP) {
+            const bool keep = keep_at((uint32_t)qi);
+            s[e] = keep ? pe : 0.f;
+            ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - rowc[128 + r]);
+          } else {
+            s[e] = pe;
+            ds[e] = pe * (dp[e] - rowc[128 + r]);
+          }
         }
       }
       second_product(Oimg, 32 * rbk, s, dv, lane);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
@@ -557,15 +617,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnP P) {
   bf16_t* dkb = reinterpret_cast<bf16_t*>(d.dk) + b * d.dk_sb + head * HD;
   bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
   store_owner(dk, dkb, d.dk_st, key, Tk, h, P.sscale);
-  store_owner(dv, dvb, d.dv_st, key, Tk, h, 1.0f);
+  store_owner(dv, dvb, d.dv_st, key, Tk, h, DROP ? P.keep_scale : 1.0f);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline bool ok_mat(const void* p, int64_t sb, int64_t st) { return p && al16(p) && sb % 8 == 0 && st % 8 == 0; }
 
+#ifndef TMI_ATTN_DROP_OCC
+#define TMI_ATTN_DROP_OCC 3
+#endif
+#ifndef TMI_ATTN_DQ_DROP_OCC
+#define TMI_ATTN_DQ_DROP_OCC 2
+#endif
+// workgroups per CU of the dropout variants (the hash needs registers: the dQ kernel spills at 3 per CU)
+constexpr int DROP_OCC = TMI_ATTN_DROP_OCC, DQ_DROP_OCC = TMI_ATTN_DQ_DROP_OCC;
+
+void set_dropout(AttnP& P) {
+  P.drop_thr = tmi_drop_thr(P.d.dropout_p);
+  P.keep_scale = tmi_keep_scale(P.drop_thr);
+  P.seed_lo = (uint32_t)P.d.dropout_seed;
+  P.seed_hi = (uint32_t)(P.d.dropout_seed >> 32);
+}
+
 int check_common(const tmi_attn_desc& d) {
   if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
-      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f)
+      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && d.dropout_p < 1.f))
     return 0;
   return ok_mat(d.q, d.q_sb, d.q_st) && ok_mat(d.k, d.k_sb, d.k_st) && ok_mat(d.v, d.v_sb, d.v_st) &&
          ok_mat(d.o, d.o_sb, d.o_st);
@@ -583,8 +659,12 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   P.dq_scale = 1.f;
   P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
   P.c2 = P.sscale * LOG2E;
+  set_dropout(P);
   dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
+  if (P.drop_thr)
+    hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
   return tmi_check_launch("tmi_attn_fwd");
 }
 
@@ -599,12 +679,19 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.dq_scale = dp->dq_scale;
   P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
   P.c2 = P.sscale * LOG2E;
+  set_dropout(P);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 gq((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, gq, dim3(256), 4 * IMG, s, P);
+  if (P.drop_thr)
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
+  else
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 3>), gq, dim3(256), 4 * IMG, s, P);
   int rc = tmi_check_launch("tmi_attn_bwd(dq)");
   if (rc) return rc;
   dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
+  if (P.drop_thr)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
+  else
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
   return tmi_check_launch("tmi_attn_bwd(dkv)");
 }

@@ -67,6 +67,36 @@ template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
   return c + x * p;
 }
 
+// ---- counter-based dropout (tf.keras.layers.Dropout sites W:160, W:205, W:342, W:411 in training).
+// TF's stateful RNG stream cannot be reproduced; the keep decision here is a pure function of
+// (seed, site-local element counter), so forward and backward regenerate the same mask and nothing is
+// stored.  One 32-bit hash serves the two elements of a counter pair (16 bits each): element e is dropped
+// when its 16-bit draw is < thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr), the
+// exact inverse of the keep probability.  The oracle restates the same integer arithmetic (oracle/dropout.py).
+__host__ __device__ __forceinline__ uint32_t tmi_mix32(uint32_t x) {  // "lowbias32" finaliser
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// cheap pair hash for the attention kernels (two multiplies, one xor-shift): draws for pair id `pid`
+__host__ __device__ __forceinline__ uint32_t tmi_pair_hash(uint32_t pid, uint32_t key) {
+  uint32_t h = (pid ^ key) * 0x9E3779B1U;
+  h ^= h >> 15;
+  h *= 0x85EBCA77U;
+  return h;
+}
+__host__ __device__ __forceinline__ uint32_t tmi_drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__host__ __device__ __forceinline__ float tmi_keep_scale(uint32_t thr) { return 65536.0f / (float)(65536u - thr); }
+// key of a stream of counters: seed (64 bit) and a 32-bit stream id (e.g. batch*heads + head; 0 for flat tensors)
+__host__ __device__ __forceinline__ uint32_t tmi_stream_key(uint64_t seed, uint32_t stream_id) {
+  return tmi_mix32((uint32_t)seed ^ tmi_mix32((uint32_t)(seed >> 32) + stream_id));
+}
+// keep decision of element `idx` (flat counter < 2^33) of a stream
+__host__ __device__ __forceinline__ bool tmi_keep(uint32_t key, uint64_t idx, uint32_t thr) {
+  const uint32_t h = tmi_pair_hash((uint32_t)(idx >> 1), key);
+  const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return r >= thr;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

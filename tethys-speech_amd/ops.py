@@ -223,14 +223,17 @@ def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale=1.0):
     return d
 
 
-def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0):
+def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0, dropout_p=0.0, dropout_seed=0):
     with _probe("attention", 4.0 * B * H * Tq * Tk * 64):
         d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
+        d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
         check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
 
 
-def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0):
+def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0,
+             dropout_p=0.0, dropout_seed=0):
     d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
     for name, field, (t, off, sb, st) in (("d_o", "do", do), ("dq", "dq", dq), ("dk", "dk", dk), ("dv", "dv", dv)):
         setattr(d, name, t.data_ptr() + off * t.element_size())
         setattr(d, f"{field}_sb", sb)
@@ -239,6 +242,13 @@ def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0
     d.dq_scale = dq_scale
     with _probe("attention", 10.0 * B * H * Tq * Tk * 64):  # algorithmic: five products (the two passes run seven)
         check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
+
+
+def dropout(x, out, rows, cols, p, seed, resid=None):
+    """out = (resid or 0) + Dropout_p(x) over [rows, cols] (row strides from the tensors); the same call on the
+    incoming gradient, with the same seed, is the backward.  See tmi_dropout in include/tethys_mi.h."""
+    check(lib().tmi_dropout(x.data_ptr(), x.stride(0), ptr(resid), resid.stride(0) if resid is not None else 0,
+                            out.data_ptr(), out.stride(0), rows, cols, p, seed, dt(x), stream()), "tmi_dropout")
 
 
 def embed_fwd(labels, table, pe, out, B, S, D, start_id):
