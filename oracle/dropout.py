@@ -23,11 +23,18 @@ def mix32(x):
     return x
 
 
+M24 = np.uint64(0xFFFFFF)
+
+
+def _mul24(a, b):
+    return ((_u32(a) & M24) * (_u32(b) & M24)) & M32
+
+
 def pair_hash(pid, key):
-    h = ((_u32(pid) ^ _u32(key)) * np.uint64(0x9E3779B1)) & M32
+    a = (_u32(pid) ^ _u32(key)) & M32
+    h = _mul24(a, 0x9E3779)
     h ^= h >> np.uint64(15)
-    h = (h * np.uint64(0x85EBCA77)) & M32
-    return h
+    return (_mul24(h, 0x85EBCB) + (a >> np.uint64(8))) & M32
 
 
 def stream_key(seed, stream_id):
@@ -73,3 +80,40 @@ def keep_attention(seed, B, H, Tq, Tk, p):
             r = np.where(k & np.uint64(1), hh >> np.uint64(16), hh & np.uint64(0xFFFF))
             out[b, h] = r >= thr
     return out
+
+
+# ---- site seeds of the Whisper step (tethys-speech_amd/whisper.py SITE_*, KernelBlocks._site_seed restated)
+SITE_BASE = {"encoder.stem": 1, "decoder.embed": 2}
+_LAYER_SITES = (("encoder.layers.", ".self_attn", 100), ("encoder.layers.", ".feed_forward", 200),
+                ("decoder.layers.", ".self_attn", 300), ("decoder.layers.", ".encoder_attn", 400),
+                ("decoder.layers.", ".feed_forward", 500))
+
+
+def site_id(name: str) -> int:
+    if name in SITE_BASE:
+        return SITE_BASE[name]
+    for head, tail, base in _LAYER_SITES:
+        if name.startswith(head) and name.endswith(tail):
+            return base + int(name[len(head):-len(tail)])
+    raise KeyError(name)
+
+
+def site_seed(base_seed: int, step: int, site: int) -> int:
+    return (base_seed + step * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class HostDropout:
+    """Mask provider for oracle.whisper_oracle.DROPOUT_PROVIDER: the masks the HIP step draws in step ``step``."""
+
+    def __init__(self, base_seed: int, step: int = 0):
+        self.base_seed, self.step = base_seed, step
+
+    def mask(self, site: str, shape, rate):
+        import torch
+        seed = site_seed(self.base_seed, self.step, site_id(site))
+        if len(shape) == 4:  # attention probabilities [B, H, Tq, Tk]
+            keep = keep_attention(seed, *shape, rate)
+        else:                # hidden states [B, T, d] as rows x d
+            rows = int(np.prod(shape[:-1]))
+            keep = keep_flat(seed, rows, shape[-1], rate).reshape(shape)
+        return torch.from_numpy(keep), keep_scale(rate)

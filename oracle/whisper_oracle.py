@@ -244,10 +244,18 @@ def conv1d_same(x, kernel, bias, stride):
     return y if bias is None else y + bias
 
 
-def dropout(x, rate, training, gen=None):
+# When set (oracle.dropout.HostDropout), every Dropout site takes its keep mask from the counter-based
+# generator the HIP kernels use, so a step WITH dropout can be compared mask for mask.
+DROPOUT_PROVIDER = None
+
+
+def dropout(x, rate, training, gen=None, site=None):
     """tf.keras.layers.Dropout: inverted dropout.  Only used when rate > 0 (perf mode)."""
     if not training or rate <= 0.0:
         return x
+    if DROPOUT_PROVIDER is not None:
+        keep, scale = DROPOUT_PROVIDER.mask(site, tuple(x.shape), rate)
+        return x * keep.to(x.dtype) * scale
     keep = (torch.rand(x.shape, generator=gen, dtype=torch.float32) >= rate).to(x.dtype)
     return x * keep / (1.0 - rate)
 
@@ -292,7 +300,7 @@ def mha(p, prefix, hidden, kv_states, mask, num_heads, attn_dropout=0.0, trainin
         else:
             scores = scores + add.to(scores.dtype)
     probs = torch.softmax(scores, dim=-1)  # W:157
-    probs = dropout(probs, attn_dropout, training)  # W:160
+    probs = dropout(probs, attn_dropout, training, site=prefix)  # W:160
     ctx = probs @ v  # W:167
     ctx = ctx.permute(0, 2, 1, 3).reshape(B, Tq, d)
     return dense(ctx, p[f"{prefix}.out_proj.kernel"], p[f"{prefix}.out_proj.bias"])  # W:174
@@ -304,7 +312,7 @@ def feed_forward(p, prefix, x, cfg, training):
     h = gelu_erf(h)
     h = dropout(h, cfg.activation_dropout, training)
     h = dense(h, p[f"{prefix}.fc2.kernel"], p[f"{prefix}.fc2.bias"])
-    return dropout(h, cfg.dropout, training)
+    return dropout(h, cfg.dropout, training, site=prefix)
 
 
 def encoder_layer(p, prefix, x, cfg, training):
@@ -339,7 +347,7 @@ def encoder(p, feats, cfg, training=True):
     x = gelu_erf(conv1d_same(x, p["encoder.conv2.kernel"], p["encoder.conv2.bias"], 2))  # W:335-336
     pe = torch.from_numpy(positional_encoding(cfg.n_ctx, cfg.d_model)).to(x.dtype)
     x = x + pe[: x.shape[1]]  # W:339
-    x = dropout(x, cfg.dropout, training)
+    x = dropout(x, cfg.dropout, training, site="encoder.stem")
     for i in range(cfg.encoder_layers):
         x = encoder_layer(p, f"encoder.layers.{i}", x, cfg, training)
     return layer_norm(x, p["encoder.layer_norm.gamma"], p["encoder.layer_norm.beta"], cfg.layer_norm_eps)
@@ -350,7 +358,7 @@ def decoder(p, ids, enc, cfg, training=True):
     x = p["decoder.embed_tokens.embeddings"][ids.long()]  # W:405
     pe = torch.from_numpy(positional_encoding(cfg.max_target_positions, cfg.d_model)).to(x.dtype)
     x = x + pe[: x.shape[1]]  # W:408
-    x = dropout(x, cfg.dropout, training)
+    x = dropout(x, cfg.dropout, training, site="decoder.embed")
     S = ids.shape[1]
     mask = torch.from_numpy(decoder_mask(S))[None]  # W:416-418
     for i in range(cfg.decoder_layers):

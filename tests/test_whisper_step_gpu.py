@@ -75,6 +75,45 @@ def test_step_gradients_match_oracle(dev, precision, T_in):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
 
 
+def test_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
+    """Training-mode dropout (W:160 attention probabilities, W:205 FFN output, W:342 / W:411 stem and embedding outputs):
+    the bf16 path draws counter-based masks inside its kernels; the oracle, fed the same generator restated on the
+    host (oracle/dropout.py), must give the same loss and gradients — for two consecutive steps, whose masks differ."""
+    from oracle import dropout as DO
+    cfg_kw = small_cfg()
+    model, ocfg, params = build("bf16", cfg_kw, dev)
+    model.enable_dropout(0.1, 0.1, seed=0xC0FFEE)
+    ocfg = O.make_config_like(ocfg, dropout=0.1, attention_dropout=0.1)
+    S, B, T_in = 12, 3, 47
+    feats, labels = O.create_dummy_pool(seed=13, n_mels=cfg_kw["n_mels"], seq_len=T_in, max_target_length=S, num_samples=B)
+    for k in params:
+        if k.endswith(".kernel"):
+            params[k] = params[k].to(torch.bfloat16).double()
+    losses = []
+    try:
+        for step in range(2):
+            O.DROPOUT_PROVIDER = DO.HostDropout(0xC0FFEE, step)
+            loss_ref, grads_ref = O.loss_and_grads(params, torch.from_numpy(feats), torch.from_numpy(labels), ocfg)
+            loss = model.forward_backward(torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev))
+            torch.cuda.synchronize()
+            lv = float(loss.item())
+            losses.append((lv, float(loss_ref)))
+            assert abs(lv - float(loss_ref)) <= 2e-2, losses
+            got = model.arena.ref_views(model.arena.g)
+            bad = {}
+            for k, gr in grads_ref.items():
+                err = float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2))
+                if err > 6e-2:
+                    bad[k] = err
+            assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    finally:
+        O.DROPOUT_PROVIDER = None
+    # the two steps drew different masks (same batch, same weights: the losses differ) and dropout is really on
+    assert abs(losses[0][1] - losses[1][1]) > 1e-4
+    O_nodrop, _ = O.loss_and_grads(params, torch.from_numpy(feats), torch.from_numpy(labels), O.make_config_like(ocfg, dropout=0.0, attention_dropout=0.0))
+    assert abs(float(O_nodrop) - losses[0][1]) > 1e-4
+
+
 def test_ten_step_loss_curve_fp32_small_dims(dev):
     """10 Adam steps (lr 1e-4, TF epsilon placement), fp32 path, against the oracle run in
     fp64 on the same pool: |dloss| <= 1e-3 per step is the BASELINE target; we hold 1e-4."""

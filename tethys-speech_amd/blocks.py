@@ -302,14 +302,39 @@ class KernelBlocks:
         ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
                           dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
 
-    def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask, score_scale=1.0):
+    # ---- dropout (training mode of the reference, W:160 / W:205 / W:342 / W:411): counter-based masks
+    # regenerated in backward (tmi_dropout, tmi_attn_*).  Off unless ``enable_dropout`` was called: with
+    # dropout on a step has no parity definition against the reference (TF's RNG stream), only against
+    # the oracle fed the same masks.
+    _drop_p = 0.0          # hidden-state dropout rate (config.dropout)
+    _drop_attn_p = 0.0     # attention-probability dropout rate (config.attention_dropout)
+    _drop_base = 0
+    _drop_step = 0
+
+    def enable_dropout(self, p, attn_p, seed=0x5EED):
+        if (p > 0 or attn_p > 0) and self.precision != "bf16":
+            raise ValueError("dropout is implemented for the bf16 (fused attention) path; fp32 is the parity mode (rates 0)")
+        self._drop_p, self._drop_attn_p, self._drop_base, self._drop_step = float(p), float(attn_p), int(seed), 0
+
+    def _site_seed(self, site: int) -> int:
+        """Seed of dropout site ``site`` in the current step (restated in oracle/dropout.py)."""
+        return (self._drop_base + self._drop_step * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def _dropout(self, x2d, out2d, site, resid=None):
+        """out = (resid or 0) + Dropout(x); no-op copy-free when the rate is 0 and out is x."""
+        self._guard_write(out2d)
+        ops.dropout(x2d, out2d, x2d.shape[0], x2d.shape[1], self._drop_p, self._site_seed(site), resid=resid)
+
+    def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask, score_scale=1.0, site=None):
         """score_scale multiplies q·kᵀ (V:349); Whisper pre-scales q instead (W:141) and passes 1."""
         d = self.hidden
         (qt, qo), (kt, ko), (vt, vo) = q, k, v
         if self.precision == "bf16":
+            dp = self._drop_attn_p if site is not None else 0.0
             ops.attn_fwd((qt, qo, Tq * qt.stride(0), qt.stride(0)), (kt, ko, Tk * kt.stride(0), kt.stride(0)),
                          (vt, vo, Tk * vt.stride(0), vt.stride(0)), (ctx2d, 0, Tq * d, d),
-                         self.ws[key], B, H, Tq, Tk, mask, score_scale=score_scale)
+                         self.ws[key], B, H, Tq, Tk, mask, score_scale=score_scale,
+                         dropout_p=dp, dropout_seed=self._site_seed(site) if dp > 0 else 0)
             return
         P = self.ws[key]
         hd = d // H
@@ -323,7 +348,7 @@ class KernelBlocks:
                      a_off=b * H * Tq * Tk, b_off=b * Tk * vt.stride(0) + vo, c_off=b * Tq * d)
 
     def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask, score_scale=1.0,
-                  q_prescaled=True):
+                  q_prescaled=True, site=None):
         d = self.hidden
         hd = d // H
         scaling = hd ** -0.5
@@ -335,7 +360,9 @@ class KernelBlocks:
                 return (t, off, T * t.stride(0), t.stride(0))
             ops.attn_bwd(m(qt, qo, Tq), m(kt, ko, Tk), m(vt, vo, Tk), m(ctx2d, 0, Tq), self.ws[key],
                          m(dctx2d, 0, Tq), m(dqt, dqo, Tq), m(dkt, dko, Tk), m(dvt, dvo, Tk), self.ws["delta"],
-                         B, H, Tq, Tk, mask, dq_scale=scaling if q_prescaled else 1.0, score_scale=score_scale)
+                         B, H, Tq, Tk, mask, dq_scale=scaling if q_prescaled else 1.0, score_scale=score_scale,
+                         dropout_p=self._drop_attn_p if site is not None else 0.0,
+                         dropout_seed=self._site_seed(site) if (site is not None and self._drop_attn_p > 0) else 0)
             return
         P = self.ws[key]
         dP = self.ws["dP"]

@@ -77,12 +77,21 @@ __host__ __device__ __forceinline__ uint32_t tmi_mix32(uint32_t x) {  // "lowbia
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-// cheap pair hash for the attention kernels (two multiplies, one xor-shift): draws for pair id `pid`
+// pair hash: 32 bits for the counter pair `pid` of a stream with key `key`.  Built on 24-bit multiplies
+// (v_mul_u32_u24 / v_mad_u32_u24 are full-rate VALU instructions, the 32-bit v_mul_lo_u32 is quarter rate): five
+// instructions per two elements inside the attention kernels, which are VALU-bound.
+__host__ __device__ __forceinline__ uint32_t tmi_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, b);
+#else
+  return (uint32_t)((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu));
+#endif
+}
 __host__ __device__ __forceinline__ uint32_t tmi_pair_hash(uint32_t pid, uint32_t key) {
-  uint32_t h = (pid ^ key) * 0x9E3779B1U;
+  const uint32_t a = pid ^ key;
+  uint32_t h = tmi_mul24(a, 0x9E3779u);
   h ^= h >> 15;
-  h *= 0x85EBCA77U;
-  return h;
+  return tmi_mul24(h, 0x85EBCBu) + (a >> 8);
 }
 __host__ __device__ __forceinline__ uint32_t tmi_drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 __host__ __device__ __forceinline__ float tmi_keep_scale(uint32_t thr) { return 65536.0f / (float)(65536u - thr); }

@@ -11,8 +11,10 @@ Two precisions:
           weights, attention in the reference's own materialised-score shape (W:147-167).
   "bf16"  perf mode — bf16 activations and bf16 weight shadows, fused flash attention,
           fp32 accumulation, fp32 gradients/optimizer state.
-Dropout (W:29-30) is not applied in either mode (rates forced to 0): TF's RNG stream cannot
-be reproduced, so a step with dropout has no parity definition.
+Dropout (W:29-30) is off by default (parity mode: TF's RNG stream cannot be reproduced, so a step with
+dropout has no parity definition against the reference).  ``enable_dropout`` turns on the
+reference's training-mode sites (W:160, W:205, W:342, W:411) on the bf16 path with counter-based masks
+(tmi_dropout / the fused attention kernels); the oracle fed the same masks is the checker.
 """
 from __future__ import annotations
 
@@ -29,6 +31,11 @@ from .blocks import Arena, KernelBlocks, _round_up
 
 
 # ----------------------------------------------------------------------------- config
+# dropout site ids (seed = f(base, step, site), KernelBlocks._site_seed; restated in oracle/dropout.py)
+SITE_ENC_STEM, SITE_DEC_EMBED = 1, 2
+SITE_ENC_ATTN, SITE_ENC_FFN, SITE_DEC_SELF, SITE_DEC_CROSS, SITE_DEC_FFN = 100, 200, 300, 400, 500
+
+
 @dataclass
 class WhisperConfig:  # W:10-45
     d_model: int = 768
@@ -312,6 +319,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             return self._forward_backward(features, labels, loss_scale, grad_ready)
         finally:
             self.end_step()
+            self._drop_step += 1  # next step draws fresh masks
 
     def _forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
                          grad_ready=None):
@@ -363,6 +371,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
                       c_sb=T * d, bias=a.param("encoder.conv2.bias"), act=1, aux_out=ws["u2"], resid=self.pe_enc_t,
                       r_ld=d, r_sb=0)
 
+        drop = self._drop_p > 0.0
+        if drop:
+            self._dropout(x, x, SITE_ENC_STEM)  # W:342
         # ---- encoder layers (W:218-236)
         for i in range(cfg.encoder_layers):
             p, k = f"encoder.layers.{i}", f"enc{i}."
@@ -371,12 +382,17 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_e)
             qkv = ws[k + "qkv"]
             self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
-                           ws[k + "ctx"], B, He, T, T, 0)
+                           ws[k + "ctx"], B, He, T, T, 0, site=SITE_ENC_ATTN + i)
             self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
             self._ln_fwd(ws[k + "x_mid"], p + ".final_layer_norm", ws[k + "xn2"], k + "ln2")
             self._dense_fwd(ws[k + "xn2"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
             nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.encoder_layers else ws["enc_x"]
-            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid"], r_ld=d)
+            if drop:  # W:205: x_mid + Dropout(fc2(g))
+                tmp = ws["dtmp"][:B * T]
+                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", tmp)
+                self._dropout(tmp, nxt, SITE_ENC_FFN + i, resid=ws[k + "x_mid"])
+            else:
+                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid"], r_ld=d)
         self._ln_fwd(ws["enc_x"], "encoder.layer_norm", ws["enc_out"], "enc_ln")
         enc_out = ws["enc_out"]
 
@@ -384,6 +400,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
         y = ws["dec0.x_in"] if cfg.decoder_layers else ws["dec_x"]
         ops.embed_fwd(labels, a.param("decoder.embed_tokens.embeddings"), self.pe_dec, y, B, S, d,
                       cfg.decoder_start_token_id)
+        if drop:
+            self._dropout(y, y, SITE_DEC_EMBED)  # W:411
         kvc = ws["kvc_all"]
         if cfg.decoder_layers:  # W:122-123 for all layers at once (see the parameter spec)
             self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc)
@@ -394,19 +412,24 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_d)
             qkv = ws[k + "qkv"]
             self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
-                           ws[k + "ctx"], B, Hd, S, S, 1)
+                           ws[k + "ctx"], B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
             self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
             # cross attention (W:278-290): k/v projections of the encoder output in every layer
             self._ln_fwd(ws[k + "x_mid"], p + ".encoder_attn_layer_norm", ws[k + "xn2"], k + "ln2")
             self._dense_fwd(ws[k + "xn2"], p + ".encoder_attn.q_proj.kernel", ws[k + "qc"], scale_cols=d, scale=scal_d)
             self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
-                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], B, Hd, S, T, 0)
+                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
             self._dense_fwd(ws[k + "ctxc"], p + ".encoder_attn.out_proj.kernel", ws[k + "x_mid2"],
                             resid=ws[k + "x_mid"], r_ld=d)
             self._ln_fwd(ws[k + "x_mid2"], p + ".final_layer_norm", ws[k + "xn3"], k + "ln3")
             self._dense_fwd(ws[k + "xn3"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
             nxt = ws[f"dec{i + 1}.x_in"] if i + 1 < cfg.decoder_layers else ws["dec_x"]
-            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid2"], r_ld=d)
+            if drop:
+                tmp = ws["dtmp"][:B * S]
+                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", tmp)
+                self._dropout(tmp, nxt, SITE_DEC_FFN + i, resid=ws[k + "x_mid2"])
+            else:
+                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid2"], r_ld=d)
         self._ln_fwd(ws["dec_x"], "decoder.layer_norm", ws["dec_out"], "dec_ln")
 
         # ---- LM head + shifted cross-entropy (W:579-600); logits become dlogits in place
@@ -441,8 +464,12 @@ class WhisperForConditionalGeneration(KernelBlocks):
             p, k = f"decoder.layers.{i}", f"dec{i}."
             Rd = B * S
             dU, dt_, dctx, dqkv = ws["dU"][:Rd], ws["dtmp"][:Rd], ws["dctx"][:Rd], ws["dqkv"][:Rd]
-            # FFN
-            self._dense_bwd(ws[k + "g"], dres, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+            # FFN (with dropout the branch sees the masked gradient: the same mask, regenerated)
+            dy = dres
+            if drop:
+                dy = dctx
+                self._dropout(dres, dy, SITE_DEC_FFN + i)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
             self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True)
             # cross attention
@@ -450,7 +477,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             dqc = ws["dtmp"][:Rd]
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
                            (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctx, (dqc, 0),
-                           (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0)
+                           (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
             dxn2 = ws["dctx"][:Rd]
             self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
             self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True)
@@ -458,7 +485,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
             qkv = ws[k + "qkv"]
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
-                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1)
+                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
             ready(p + ".self_attn_layer_norm.gamma")
@@ -467,6 +494,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
             # (K = L*2d) for the cross-attention k/v projections of all layers
             self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
             ready("decoder.cross_kv.kernel")
+        if drop:
+            self._dropout(dres, dres, SITE_DEC_EMBED)
         ops.embed_bwd(labels, dres, a.grad("decoder.embed_tokens.embeddings"), B, S, d, cfg.decoder_start_token_id)
         ready("decoder.embed_tokens.embeddings")
 
@@ -480,18 +509,24 @@ class WhisperForConditionalGeneration(KernelBlocks):
         for i in reversed(range(cfg.encoder_layers)):
             p, k = f"encoder.layers.{i}", f"enc{i}."
             dU, dt_, dctx, dqkv = ws["dU"][:R], ws["dtmp"][:R], ws["dctx"][:R], ws["dqkv"][:R]
-            self._dense_bwd(ws[k + "g"], dres, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+            dy = dres
+            if drop:
+                dy = dctx
+                self._dropout(dres, dy, SITE_ENC_FFN + i)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
             self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True)
             self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
             qkv = ws[k + "qkv"]
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
-                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0)
+                           ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0, site=SITE_ENC_ATTN + i)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
             ready(p + ".self_attn_layer_norm.gamma")
 
         # ---- stem backward: x0 = gelu(u2) + PE ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(x)
+        if drop:
+            self._dropout(dres, dres, SITE_ENC_STEM)
         du2pad, dh1pad = ws["du2pad"], ws["dh1pad"]
         du2 = du2pad[:, 1:]  # row 0 of every batch stays zero (the "t-1" term of the first output)
         # one launch over the B per-sample spans (du2 skips the zero row 0 of every sample)
