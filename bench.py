@@ -9,6 +9,8 @@ refresh on one synthetic batch already resident in HBM (BASELINE.json configs[1]
 "small" as the reference defines it — 768/12h/3072, 4+4 layers, W:13-18 — bf16 compute,
 per-GPU batch 8, 30 s clips = [8, 80, 3000] features + [8, 100] labels).  Weak scaling: the
 per-GPU batch is fixed, value = 30 s * 8 * N * K / max-over-ranks wall time.
+The step runs as the reference's does (training=True): its Dropout layers (W:29-30, rates 0.1 / 0.1) are
+active, with counter-based masks (--dropout off gives the rates-0 configuration the loss-curve parity tests pin).
 
 Also reported on the same JSON line:
   roofline      the dominant kernel class (the MFMA GEMM, tmi_gemm): algorithmic FLOPs of
@@ -20,8 +22,8 @@ Also reported on the same JSON line:
                 against the MFMA peak by algorithmic flop; Adam, LayerNorm, bias column sums and the
                 cross-entropy against the 8 TB/s HBM peak by algorithmic bytes).
   cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the
-                host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up +
-                2 timed steps of the same model and clip length).
+                host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up + up to
+                6 timed steps, ~14 s, of the same model and clip length; dropout rates 0).
 """
 import argparse
 import json
@@ -129,6 +131,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2"],
                     help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips)")
+    ap.add_argument("--dropout", choices=["off", "reference"], default="reference",
+                    help="reference (default): the reference's training-mode Dropout layers (W:29-30, rates 0.1 / 0.1) are "
+                         "active, as in its distributed_train_step (training=True), with counter-based masks; "
+                         "off: rates 0, the configuration the loss-curve parity tests pin")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -153,6 +159,8 @@ def main():
     model = whisper.create_whisper_model(args.model_type, device=dev, precision=args.precision, seed=1234)
     strategy.broadcast_parameters(model.arena.p)
     model.refresh_shadows()
+    if args.dropout == "reference":
+        model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=1234 * 1000003 + rank)
     opt = optim.Adam(learning_rate=1e-4)
     ds = create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True)
     it = iter(ds)
@@ -247,6 +255,8 @@ def main():
             "config": {"workload": f"whisper-{args.model_type}-ref (reference '{args.model_type}': {shape_note}) "
                                    f"train step, per-GPU batch {args.batch_size}, 30 s clips [80x3000], S=100",
                        "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
+                       "dropout": ("reference rates (0.1 / 0.1), counter-based masks" if args.dropout == "reference"
+                                   else "off (rates 0: the configuration the parity tests pin)"),
                        "step_tflops": gf_sample * gb * args.steps / dt / 1e3 if gf_sample else None},
         }
         if roof is not None:

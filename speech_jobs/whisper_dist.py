@@ -25,6 +25,8 @@ def main(argv=None):
     parser.add_argument("--batch_size", type=int, default=1, help="batch size per replica, default is set 1")
     parser.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     parser.add_argument("--model_type", default="small")
+    parser.add_argument("--dropout", choices=["reference", "off"], default=None,
+                        help="reference = the Dropout layers of W:29-30 active (default on the bf16 path); off = parity mode")
     parser.add_argument("--tensor_logs", default=None,
                         help="directory for the tensor-size / skewness report (whisper_dist_tensorsize.py's files)")
     parser.add_argument("--resume_from", default=None, help="checkpoint to restore before training")
@@ -56,7 +58,8 @@ def main(argv=None):
     model = train.train_whisper(strategy, model_type=args.model_type, batch_size=args.batch_size,
                                 num_batches=args.num_batches, precision=args.precision, device=device,
                                 checkpoint_dir=os.path.join(workspace, "checkpoints"),
-                                tensor_log_dir=args.tensor_logs, resume_from=args.resume_from)
+                                tensor_log_dir=args.tensor_logs, resume_from=args.resume_from,
+                                dropout=None if args.dropout is None else args.dropout == "reference")
     jct = time.time() - start_time
     print("Training completed.")
     print("jct:", jct)

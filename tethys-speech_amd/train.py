@@ -103,7 +103,7 @@ def make_train_step(strategy, model, optimizer, example_inputs, warmup=2):
 def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4, *, batch_size=1,
                   num_batches=40, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print, seed=1234,
                   model_overrides=None, seq_len=3000, max_target_length=100, tensor_log_dir=None,
-                  resume_from=None):
+                  resume_from=None, dropout=None):
     """W:894-958: model + Adam(1e-4), dummy dataset, per-step log line, checkpoint at epoch end.
     ``tensor_log_dir``: also write the tensor-size / skewness report of the reference's
     ``whisper_dist_tensorsize.py`` there (computed from shapes, see tensorsize.py).
@@ -112,6 +112,12 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
                                  **(model_overrides or {}))
     strategy.broadcast_parameters(model.arena.p)
     model.refresh_shadows()
+    # the reference trains with its Dropout layers active (W:29-30, training=True): on by default on the bf16
+    # path, every replica with its own mask stream; ``dropout=False`` is the parity setting
+    if dropout is None:
+        dropout = precision == "bf16"
+    if dropout:
+        model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=seed * 1000003 + strategy.rank)
     optimizer = Adam(learning_rate=learning_rate)
     if resume_from:
         load_checkpoint(model, optimizer, resume_from)
