@@ -83,6 +83,9 @@ def bench_wav2vec2(args, strategy, dev, rank, world):
     model = wav2vec2.create_full_model("pretraining", size, device=dev, precision=args.precision, seed=1234)
     strategy.broadcast_parameters(model.arena.p)
     model.refresh_shadows()
+    if args.dropout == "reference":
+        c = model.config
+        model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=1234 * 1000003 + rank, act_p=c.activation_dropout)
     opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
     ds = W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234)
     it = iter(ds)
@@ -116,6 +119,7 @@ def bench_wav2vec2(args, strategy, dev, rank, world):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]",
+                       "dropout": "reference rates (0.1 / 0.1 / 0.1)" if args.dropout == "reference" else "off",
                        "global_batch": gb, "parallelism": f"dp{world}", "last_loss": float(loss.item())}}))
     if world > 1:
         torch.distributed.destroy_process_group()

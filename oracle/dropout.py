@@ -102,15 +102,30 @@ def site_seed(base_seed: int, step: int, site: int) -> int:
     return (base_seed + step * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
-class HostDropout:
-    """Mask provider for oracle.whisper_oracle.DROPOUT_PROVIDER: the masks the HIP step draws in step ``step``."""
+# ---- Wav2Vec2 sites (tethys-speech_amd/wav2vec2.py SITE_*)
+W2V_SITE_BASE = {"feature_extractor": 1, "feature_projection": 2, "project_hid": 3, "project_q": 4}
+_W2V_LAYER_SITES = ((".attention", 100), (".attention_output", 200), (".intermediate", 300), (".output", 400))
 
-    def __init__(self, base_seed: int, step: int = 0):
-        self.base_seed, self.step = base_seed, step
+
+def w2v_site_id(name: str) -> int:
+    if name in W2V_SITE_BASE:
+        return W2V_SITE_BASE[name]
+    head = "encoder.layers."
+    for tail, base in _W2V_LAYER_SITES:
+        if name.startswith(head) and name.endswith(tail) and name[len(head):-len(tail)].isdigit():
+            return base + int(name[len(head):-len(tail)])
+    raise KeyError(name)
+
+
+class HostDropout:
+    """Mask provider for the oracles' DROPOUT_PROVIDER hooks: the masks the HIP step draws in step ``step``."""
+
+    def __init__(self, base_seed: int, step: int = 0, site_id=site_id):
+        self.base_seed, self.step, self.site_id = base_seed, step, site_id
 
     def mask(self, site: str, shape, rate):
         import torch
-        seed = site_seed(self.base_seed, self.step, site_id(site))
+        seed = site_seed(self.base_seed, self.step, self.site_id(site))
         if len(shape) == 4:  # attention probabilities [B, H, Tq, Tk]
             keep = keep_attention(seed, *shape, rate)
         else:                # hidden states [B, T, d] as rows x d

@@ -219,6 +219,18 @@ def group_norm(x, gamma, beta, groups, eps=1e-5):
     return gamma * xn + beta
 
 
+# When set (oracle.dropout.HostDropout with the Wav2Vec2 site table), the reference's Dropout layers (V:296, V:359,
+# V:393, V:396, V:431, V:560, V:779) are applied with the counter-based masks the HIP kernels draw; None = rates 0.
+DROPOUT_PROVIDER = None
+
+
+def _drop(x, rate, site):
+    if DROPOUT_PROVIDER is None or rate <= 0.0:
+        return x
+    keep, scale = DROPOUT_PROVIDER.mask(site, tuple(x.shape), rate)
+    return x * keep.to(x.dtype) * scale
+
+
 def feature_extractor(p, audio, cfg):
     """V:283-298."""
     x = audio.unsqueeze(-1)
@@ -229,10 +241,11 @@ def feature_extractor(p, audio, cfg):
         x = gelu_erf(group_norm(x, p[f"{pre}.norm.gamma"], p[f"{pre}.norm.beta"], G))
     pos = conv1d_same(x, p["feature_extractor.pos_conv_embed.kernel"], p["feature_extractor.pos_conv_embed.bias"], 1, groups=G)
     x = x + pos
-    return layer_norm(x, p["feature_extractor.layer_norm.gamma"], p["feature_extractor.layer_norm.beta"], cfg.layer_norm_eps)
+    x = layer_norm(x, p["feature_extractor.layer_norm.gamma"], p["feature_extractor.layer_norm.beta"], cfg.layer_norm_eps)
+    return _drop(x, cfg.hidden_dropout, "feature_extractor")  # V:296
 
 
-def attention(p, prefix, x, num_heads):
+def attention(p, prefix, x, num_heads, attn_dropout=0.0):
     """V:333-376 (attention_mask None in training)."""
     B, T, H = x.shape
     hd = H // num_heads
@@ -245,7 +258,7 @@ def attention(p, prefix, x, num_heads):
 
     q, k, v = split(q), split(k), split(v)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(hd)  # V:348-349
-    ctx = torch.softmax(s, dim=-1) @ v
+    ctx = _drop(torch.softmax(s, dim=-1), attn_dropout, prefix) @ v  # V:359
     ctx = ctx.permute(0, 2, 1, 3).reshape(B, T, H)
     return dense(ctx, p[f"{prefix}.out_proj.kernel"], p[f"{prefix}.out_proj.bias"])
 
@@ -253,11 +266,13 @@ def attention(p, prefix, x, num_heads):
 def encoder_layer(p, prefix, x, cfg):
     """V:419-439 (do_stable_layer_norm=True branch)."""
     h = layer_norm(x, p[f"{prefix}.attention_layer_norm.gamma"], p[f"{prefix}.attention_layer_norm.beta"], cfg.layer_norm_eps)
-    x = x + attention(p, f"{prefix}.attention", h, cfg.num_attention_heads)
+    x = x + _drop(attention(p, f"{prefix}.attention", h, cfg.num_attention_heads, cfg.attention_dropout),
+                  cfg.hidden_dropout, f"{prefix}.attention_output")  # V:431
     h = layer_norm(x, p[f"{prefix}.feed_forward_layer_norm.gamma"], p[f"{prefix}.feed_forward_layer_norm.beta"], cfg.layer_norm_eps)
     h = gelu_erf(dense(h, p[f"{prefix}.feed_forward.intermediate_dense.kernel"], p[f"{prefix}.feed_forward.intermediate_dense.bias"]))
+    h = _drop(h, cfg.activation_dropout, f"{prefix}.intermediate")  # V:393
     h = dense(h, p[f"{prefix}.feed_forward.output_dense.kernel"], p[f"{prefix}.feed_forward.output_dense.bias"])
-    return x + h
+    return x + _drop(h, cfg.hidden_dropout, f"{prefix}.output")  # V:396
 
 
 def quantizer(p, hidden, cfg, force_idx=None):
@@ -288,7 +303,8 @@ def quantizer(p, hidden, cfg, force_idx=None):
 def projection_head(p, name, x, cfg):
     """V:557-561."""
     h = dense(x, p[f"{name}.dense.kernel"], p[f"{name}.dense.bias"])
-    return layer_norm(h, p[f"{name}.layer_norm.gamma"], p[f"{name}.layer_norm.beta"], cfg.layer_norm_eps)
+    h = layer_norm(h, p[f"{name}.layer_norm.gamma"], p[f"{name}.layer_norm.beta"], cfg.layer_norm_eps)
+    return _drop(h, cfg.hidden_dropout, name)  # V:560
 
 
 def forward(p, audio, cfg, force_idx=None):
@@ -297,6 +313,7 @@ def forward(p, audio, cfg, force_idx=None):
     feats = feature_extractor(p, audio.to(dtype), cfg)
     h = dense(feats, p["feature_projection.kernel"], p["feature_projection.bias"])
     h = layer_norm(h, p["feature_projection_layer_norm.gamma"], p["feature_projection_layer_norm.beta"], cfg.layer_norm_eps)
+    h = _drop(h, cfg.hidden_dropout, "feature_projection")  # V:779
     quantized, idx, perplexity, dists = quantizer(p, h, cfg, force_idx)  # on the projected features (V:784)
     x = h
     for i in range(cfg.num_hidden_layers):

@@ -22,6 +22,8 @@ def main(argv=None):
     parser.add_argument("--batch_size", type=int, default=1, help="batch size per replica, default is set 1")
     parser.add_argument("--model_size", type=str, default="small", choices=["tiny", "small", "base"])
     parser.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    parser.add_argument("--dropout", choices=["reference", "off"], default=None,
+                        help="reference = the Dropout layers of V:69-71 active (default on the bf16 path); off = parity mode")
     args = parser.parse_args(argv)
 
     import torch
@@ -48,7 +50,8 @@ def main(argv=None):
     start_time = time.time()
     train.train_wav2vec2(strategy, model_type="pretraining", model_size=args.model_size, batch_size=args.batch_size,
                          num_batches=args.num_batches, precision=args.precision, device=device,
-                         checkpoint_dir=os.path.join(workspace, "checkpoints"))
+                         checkpoint_dir=os.path.join(workspace, "checkpoints"),
+                         dropout=None if args.dropout is None else args.dropout == "reference")
     jct = time.time() - start_time
     print("Training completed.")
     print("jct:", jct)

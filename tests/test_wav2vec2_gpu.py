@@ -251,6 +251,45 @@ def test_wav2vec2_step_gradients_match_oracle(dev, precision):
     assert float(got["quantizer.projection.kernel"].abs().max()) == 0.0  # no gradient path (V:631-638)
 
 
+def test_wav2vec2_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
+    """Training-mode dropout of the Wav2Vec2 step (V:296, V:359, V:393, V:396, V:431, V:560, V:779; rates 0.1) on the
+    bf16 path against the oracle fed the same counter-based masks (and, as in the rates-0 test, the kernel's codebook choices)."""
+    from oracle import dropout as DO
+    model, ocfg, params = build("bf16", dev)
+    model.enable_dropout(0.1, 0.1, seed=0xBADC0DE, act_p=0.1)
+    B, T_in = 3, 400
+    pool = V.create_dummy_pool(seed=9, num_samples=B, length=T_in)
+    T = V.feature_lengths(ocfg, T_in)[-1]
+    neg = V.sample_negative_indices(np.random.default_rng(1), B, T, ocfg.num_negatives)
+    for k in params:
+        if k.endswith(".kernel"):
+            params[k] = params[k].to(torch.bfloat16).double()
+    try:
+        for step in range(2):
+            loss = model.forward_backward(torch.from_numpy(pool).to(dev), torch.from_numpy(neg).to(dev), num_replicas=2)
+            torch.cuda.synchronize()
+            kidx = model.ws["code_idx"].cpu().long().reshape(B, T, -1)
+            V.DROPOUT_PROVIDER = DO.HostDropout(0xBADC0DE, step, DO.w2v_site_id)
+            loss_ref, grads_ref, out = V.loss_and_grads(params, torch.from_numpy(pool), torch.from_numpy(neg), ocfg,
+                                                        num_replicas=2, force_idx=kidx)
+            assert float((kidx != out["code_indices"]).float().mean()) == 0.0
+            lv, lr = float(loss.item()), float(loss_ref)
+            assert abs(lv - lr) <= 1e-2 * abs(lr), (step, lv, lr)
+            got = model.arena.ref_views(model.arena.g)
+            nmax = max(float(g.norm()) for g in grads_ref.values())
+            bad = {}
+            for k, gr in grads_ref.items():
+                err = float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2 * nmax))
+                if err > 6e-2:
+                    bad[k] = err
+            assert not bad, (step, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+    finally:
+        V.DROPOUT_PROVIDER = None
+    # dropout is really on: the rates-0 loss of the same batch differs
+    l0, _, _ = V.loss_and_grads(params, torch.from_numpy(pool), torch.from_numpy(neg), ocfg, num_replicas=2, force_idx=kidx)
+    assert abs(float(l0) - lr) > 1e-3 * abs(lr)
+
+
 def test_wav2vec2_five_step_loss_curve_fp32(dev):
     """Clip-by-global-norm, clipnorm and Adam(3e-5, eps 1e-8) over 5 steps vs the oracle (fp64)."""
     import tethys_speech_amd  # noqa: F401

@@ -308,22 +308,25 @@ class KernelBlocks:
     # the oracle fed the same masks.
     _drop_p = 0.0          # hidden-state dropout rate (config.dropout)
     _drop_attn_p = 0.0     # attention-probability dropout rate (config.attention_dropout)
+    _drop_act_p = 0.0      # FFN-intermediate rate (Wav2Vec2 activation_dropout, V:393; Whisper's is 0.0, W:31)
     _drop_base = 0
     _drop_step = 0
 
-    def enable_dropout(self, p, attn_p, seed=0x5EED):
-        if (p > 0 or attn_p > 0) and self.precision != "bf16":
+    def enable_dropout(self, p, attn_p, seed=0x5EED, act_p=0.0):
+        if (p > 0 or attn_p > 0 or act_p > 0) and self.precision != "bf16":
             raise ValueError("dropout is implemented for the bf16 (fused attention) path; fp32 is the parity mode (rates 0)")
-        self._drop_p, self._drop_attn_p, self._drop_base, self._drop_step = float(p), float(attn_p), int(seed), 0
+        self._drop_p, self._drop_attn_p, self._drop_act_p = float(p), float(attn_p), float(act_p)
+        self._drop_base, self._drop_step = int(seed), 0
 
     def _site_seed(self, site: int) -> int:
         """Seed of dropout site ``site`` in the current step (restated in oracle/dropout.py)."""
         return (self._drop_base + self._drop_step * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
-    def _dropout(self, x2d, out2d, site, resid=None):
-        """out = (resid or 0) + Dropout(x); no-op copy-free when the rate is 0 and out is x."""
+    def _dropout(self, x2d, out2d, site, resid=None, p=None):
+        """out = (resid or 0) + Dropout_p(x) at dropout site ``site`` (p defaults to the hidden-state rate)."""
         self._guard_write(out2d)
-        ops.dropout(x2d, out2d, x2d.shape[0], x2d.shape[1], self._drop_p, self._site_seed(site), resid=resid)
+        ops.dropout(x2d, out2d, x2d.shape[0], x2d.shape[1], self._drop_p if p is None else p, self._site_seed(site),
+                    resid=resid)
 
     def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask, score_scale=1.0, site=None):
         """score_scale multiplies q·kᵀ (V:349); Whisper pre-scales q instead (W:141) and passes 1."""

@@ -208,7 +208,7 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
 
 def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_epochs=1, learning_rate=3e-5, *,
                    batch_size=1, num_batches=5, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print,
-                   seed=1234, clip_samples=32000, model_overrides=None):
+                   seed=1234, clip_samples=32000, model_overrides=None, dropout=None):
     """V:1263-1376: model + Adam(3e-5, eps 1e-8, clipnorm 1), 50 x 2 s dummy clips, per-step log
     line, checkpoint every 50 steps and at the end."""
     import numpy as np
@@ -218,6 +218,11 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
                               **(model_overrides or {}))
     strategy.broadcast_parameters(model.arena.p)
     model.refresh_shadows()
+    if dropout is None:  # the reference trains with its Dropout layers active (V:69-71); rates 0 is the parity setting
+        dropout = precision == "bf16"
+    if dropout:
+        c = model.config
+        model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=seed * 1000003 + strategy.rank, act_p=c.activation_dropout)
     optimizer = Adam(learning_rate=learning_rate, epsilon=1e-8)
     ds = W2VDummyDataset(batch_size, length=clip_samples, device=device, rank=strategy.rank, world=strategy.world, seed=seed)
     rng = np.random.default_rng(seed + 1)

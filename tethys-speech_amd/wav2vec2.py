@@ -49,6 +49,15 @@ class Wav2Vec2Config:  # V:24-128 (fields read by the pre-training path)
     contrastive_logits_temperature: float = 0.1
     num_negatives: int = 100
     diversity_loss_weight: float = 0.1
+    hidden_dropout: float = 0.1       # V:69-71; applied only after enable_dropout (bf16 path), see blocks.py
+    activation_dropout: float = 0.1
+    attention_dropout: float = 0.1
+
+
+# dropout site ids (KernelBlocks._site_seed; restated in oracle/dropout.py): V:296, V:779, V:560 (x2), then per
+# layer V:359 (attention probabilities), V:431 (attention output), V:393 (FFN intermediate), V:396 (FFN output)
+SITE_FE, SITE_FP, SITE_PH, SITE_PQ = 1, 2, 3, 4
+SITE_ATTN, SITE_ATTN_OUT, SITE_FFN_MID, SITE_FFN_OUT = 100, 200, 300, 400
 
 
 def make_config(model_size: str = "small", **overrides) -> Wav2Vec2Config:
@@ -280,6 +289,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             return self._forward_backward(audio, neg_indices, num_replicas)
         finally:
             self.end_step()
+            self._drop_step += 1
 
     def _forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
         """One replica's V:1199-1240: returns the device scalar ``scaled_loss`` =
@@ -327,10 +337,16 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                  a_sb=B * self.Tpp * Cg, b_sb=k * Cg * Cg, c_sb=B * self.Tpp * Cg)
         ops.group_unpack(ws["yg"], a.param("feature_extractor.pos_conv_embed.bias"), h_last, ws["hp"], B, T, C, Gn,
                          self.Tpp, 0)
+        drop = self._drop_p > 0.0
+        pa = self._drop_act_p
         self._ln_fwd(ws["hp"], "feature_extractor.layer_norm", ws["feats"], "fe_ln")
+        if drop:
+            self._dropout(ws["feats"], ws["feats"], SITE_FE)  # V:296
         self._dense_fwd(ws["feats"], "feature_projection.kernel", ws["fp_pre"])
         hproj = ws["enc0.x_in"] if cfg.num_hidden_layers else ws["enc_x"]  # the encoder's input IS the projection
         self._ln_fwd(ws["fp_pre"], "feature_projection_layer_norm", hproj, "fp_ln")
+        if drop:
+            self._dropout(hproj, hproj, SITE_FP)  # V:779 (the quantiser sees the dropped features too, V:784)
 
         # ---- quantiser on the projected features (V:784): no gradient flows back through it
         Gq, Nc = cfg.num_codevector_groups, cfg.num_codevectors_per_group
@@ -340,6 +356,8 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                        Gq, Nc, gd)
         self._dense_fwd(ws["quant"], "project_q.dense.kernel", ws["pq_pre"])
         self._ln_fwd(ws["pq_pre"], "project_q.layer_norm", ws["pq"], "pq_ln")
+        if drop:
+            self._dropout(ws["pq"], ws["pq"], SITE_PQ)  # V:560
 
         # ---- encoder (V:419-439, stable layer norm)
         for i in range(cfg.num_hidden_layers):
@@ -351,18 +369,30 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                      bias=a.param(p + ".attention.qkv3.bias"), bias_sb=H)
             qkv = ws[kk + "qkv"]
             self._attn_fwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
-                           ws[kk + "ctx"], B, Hh, T, T, 0, score_scale=sscale)
-            self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws[kk + "x_mid"], resid=x_in, r_ld=H)
+                           ws[kk + "ctx"], B, Hh, T, T, 0, score_scale=sscale, site=SITE_ATTN + i)
+            if drop:  # V:431: x + Dropout(attention output)
+                self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws["dtmp"])
+                self._dropout(ws["dtmp"], ws[kk + "x_mid"], SITE_ATTN_OUT + i, resid=x_in)
+            else:
+                self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws[kk + "x_mid"], resid=x_in, r_ld=H)
             self._ln_fwd(ws[kk + "x_mid"], p + ".feed_forward_layer_norm", ws[kk + "xn2"], kk + "ln2")
             self._dense_fwd(ws[kk + "xn2"], p + ".feed_forward.intermediate_dense.kernel", ws[kk + "g"], act=1,
                             aux_out=ws[kk + "u"])
+            if pa > 0.0:
+                self._dropout(ws[kk + "g"], ws[kk + "g"], SITE_FFN_MID + i, p=pa)  # V:393
             nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.num_hidden_layers else ws["enc_x"]
-            self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", nxt, resid=ws[kk + "x_mid"], r_ld=H)
+            if drop:  # V:396
+                self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", ws["dtmp"])
+                self._dropout(ws["dtmp"], nxt, SITE_FFN_OUT + i, resid=ws[kk + "x_mid"])
+            else:
+                self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", nxt, resid=ws[kk + "x_mid"], r_ld=H)
 
         # ---- projection head + contrastive loss (V:550-561, V:866-899)
         pd = cfg.proj_codevector_dim
         self._dense_fwd(ws["enc_x"], "project_hid.dense.kernel", ws["ph_pre"])
         self._ln_fwd(ws["ph_pre"], "project_hid.layer_norm", ws["ph"], "ph_ln")
+        if drop:
+            self._dropout(ws["ph"], ws["ph"], SITE_PH)  # V:560
         S = ws["S"]
         ops.gemm(ws["ph"], ws["pq"], S, T, T, pd, pd, 1, 1, pd, T, nbatch=B, a_sb=T * pd, b_sb=T * pd, c_sb=T * T)
         Nn = neg_indices.shape[1]
@@ -381,6 +411,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # d ph = dS · pq ; d pq = dSᵀ · ph   (per batch)
         ops.gemm(dS, ws["pq"], ws["dph"], T, pd, T, T, 1, pd, 1, pd, nbatch=B, a_sb=T * T, b_sb=T * pd, c_sb=T * pd)
         ops.gemm(dS, ws["ph"], ws["dpq"], T, pd, T, 1, T, pd, 1, pd, nbatch=B, a_sb=T * T, b_sb=T * pd, c_sb=T * pd)
+        if drop:
+            self._dropout(ws["dpq"], ws["dpq"], SITE_PQ)
+            self._dropout(ws["dph"], ws["dph"], SITE_PH)
         # project_q branch -> codebook
         self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd"], "pq_ln", False)
         self._dense_bwd(ws["quant"], ws["dpd"], "project_q.dense.kernel", ws["dquant"])
@@ -393,14 +426,24 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         for i in reversed(range(cfg.num_hidden_layers)):
             p, kk = f"encoder.layers.{i}", f"enc{i}."
             dU, dt_, dctx, dqkv = ws["dU"], ws["dtmp"], ws["dctx"], ws["dqkv"]
-            self._dense_bwd(ws[kk + "g"], dres, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"])
+            dy = dres
+            if drop:  # the branch sees the masked gradient (same mask, regenerated)
+                dy = dctx
+                self._dropout(dres, dy, SITE_FFN_OUT + i)
+            self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"])
+            if pa > 0.0:  # d gelu(u) = mask/keep * d g: the epilogue already multiplied by gelu'(u); elementwise factors commute
+                self._dropout(dU, dU, SITE_FFN_MID + i, p=pa)
             self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_)
             self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True)
-            self._dense_bwd(ws[kk + "ctx"], dres, p + ".attention.out_proj.kernel", dctx)
+            dy = dres
+            if drop:
+                dy = dt_
+                self._dropout(dres, dy, SITE_ATTN_OUT + i)
+            self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx)
             qkv = ws[kk + "qkv"]
             self._attn_bwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
                            ws[kk + "ctx"], dctx, (dqkv, 0), (dqkv, H), (dqkv, 2 * H), B, Hh, T, T, 0, score_scale=sscale,
-                           q_prescaled=False)
+                           q_prescaled=False, site=SITE_ATTN + i)
             # three separate kernels: wgrad / bias grad batched over the blocks, dgrad summed over them
             wq, _ = self.W(p + ".attention.qkv3.kernel")
             gq = a.grad(p + ".attention.qkv3.kernel")
@@ -412,12 +455,17 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                 ops.bias_grad(dqkv, gqb)
 
             self._run_on_side(qkv_weight_grads, dqkv)
+            self._guard_write(dt_)
             ops.gemm(dqkv, wq, dt_, R, H, H, 3 * H, 1, 1, H, H, kbatch=3, a_skb=H, b_skb=H * H)
             self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True)
 
         # hproj feeds the encoder only (the quantiser branch is non-differentiable)
+        if drop:
+            self._dropout(dres, dres, SITE_FP)
         self._ln_bwd(dres, ws["fp_pre"], "feature_projection_layer_norm", ws["dtmp"], "fp_ln", False)
         self._dense_bwd(ws["feats"], ws["dtmp"], "feature_projection.kernel", ws["dfeats"])
+        if drop:
+            self._dropout(ws["dfeats"], ws["dfeats"], SITE_FE)
         self._ln_bwd(ws["dfeats"], ws["hp"], "feature_extractor.layer_norm", ws["dhp"], "fe_ln", False)
         dhp = ws["dhp"]
         # hp = h_last + posconv(h_last) + bias
