@@ -244,8 +244,6 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             losses.append(lv)
             log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
                 f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
-            if report is not None:
-                report.log_step(step)
             step += 1
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
                 os.makedirs(checkpoint_dir, exist_ok=True)
