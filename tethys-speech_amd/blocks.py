@@ -317,6 +317,7 @@ class KernelBlocks:
             raise ValueError("dropout is implemented for the bf16 (fused attention) path; fp32 is the parity mode (rates 0)")
         self._drop_p, self._drop_attn_p, self._drop_act_p = float(p), float(attn_p), float(act_p)
         self._drop_base, self._drop_step = int(seed), 0
+        self._ws_key = None  # the workspace layout depends on the mode: lay it out again on the next step
 
     def _site_seed(self, site: int) -> int:
         """Seed of dropout site ``site`` in the current step (restated in oracle/dropout.py)."""

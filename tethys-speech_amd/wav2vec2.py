@@ -264,6 +264,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self._buf("loss", (1,), f32)
         # backward scratch
         self._buf("dres", (R, H)); self._buf("dtmp", (R, H)); self._buf("dctx", (R, H))
+        if self._drop_p > 0.0:  # masked gradient copies (dropout mode), alternating by layer: see whisper.py
+            for nm in ("dyd_f0", "dyd_f1", "dyd_a0", "dyd_a1"):
+                self._buf(nm, (R, H))
         self._buf("dqkv", (R, 3 * H)); self._buf("dU", (R, ff))
         self._buf("dph", (R, pd)); self._buf("dpq", (R, pd)); self._buf("dpd", (R, pd))
         self._buf("dquant", (R, cd))
@@ -428,7 +431,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             dU, dt_, dctx, dqkv = ws["dU"], ws["dtmp"], ws["dctx"], ws["dqkv"]
             dy = dres
             if drop:  # the branch sees the masked gradient (same mask, regenerated)
-                dy = dctx
+                dy = ws[f"dyd_f{i & 1}"]
                 self._dropout(dres, dy, SITE_FFN_OUT + i)
             self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"])
             if pa > 0.0:  # d gelu(u) = mask/keep * d g: the epilogue already multiplied by gelu'(u); elementwise factors commute
@@ -437,7 +440,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True)
             dy = dres
             if drop:
-                dy = dt_
+                dy = ws[f"dyd_a{i & 1}"]
                 self._dropout(dres, dy, SITE_ATTN_OUT + i)
             self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx)
             qkv = ws[kk + "qkv"]

@@ -280,6 +280,11 @@ class WhisperForConditionalGeneration(KernelBlocks):
         if self.precision == "bf16":
             self._buf("lmh_dx32", (Rd, d), f32)  # split-K accumulator of the LM-head dgrad
         self._buf("dctx", (Rm, d))
+        if self._drop_p > 0.0:
+            # masked copies of the residual-stream gradient (dropout mode): two buffers used by alternate layers, so a
+            # layer's mask pass does not have to wait for the previous layer's weight gradient, which still reads its copy
+            self._buf("dyd0", (Rm, d))
+            self._buf("dyd1", (Rm, d))
         self._buf("dqkv", (Rm, 3 * d))
         Lkv = max(1, cfg.decoder_layers) * 2 * d
         self._buf("kvc_all", (R, Lkv))   # cross-attention k/v of every decoder layer, side by side
@@ -467,7 +472,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             # FFN (with dropout the branch sees the masked gradient: the same mask, regenerated)
             dy = dres
             if drop:
-                dy = dctx
+                dy = ws[f"dyd{i & 1}"][:Rd]
                 self._dropout(dres, dy, SITE_DEC_FFN + i)
             self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
             self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
@@ -511,7 +516,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             dU, dt_, dctx, dqkv = ws["dU"][:R], ws["dtmp"][:R], ws["dctx"][:R], ws["dqkv"][:R]
             dy = dres
             if drop:
-                dy = dctx
+                dy = ws[f"dyd{i & 1}"][:R]
                 self._dropout(dres, dy, SITE_ENC_FFN + i)
             self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
             self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_)
