@@ -268,3 +268,35 @@ def test_w2v_clipping_rules():
     assert torch.allclose(c["a"], torch.tensor([0.3, 0.4]))  # norm below the clip: untouched
     e = V2.clip_by_norm_each(g, 1.0)
     assert torch.allclose(e["a"], g["a"] / 5) and torch.allclose(e["b"], g["b"] / 12)
+
+
+# ----------------------------------------------------------------------------- dropout generator
+def test_dropout_generator_known_answers_and_statistics():
+    """The counter-based dropout generator (csrc/tmi_common.h, restated in oracle/dropout.py) is part of the
+    step's definition when dropout is on: pin it with frozen vectors, and check that it behaves like independent
+    Bernoulli draws (rate, adjacent / cross-row / cross-stream / cross-step correlation)."""
+    from oracle import dropout as D
+    assert [int(D.pair_hash(i, k)) for i, k in ((0, 0), (1, 0), (12345, 0xDEADBEEF), (0xFFFFFFFF, 0x12345678))] == \
+        [0, 3944701879, 4262915128, 3372026424]
+    assert (int(D.mix32(1)), int(D.mix32(0xDEADBEEF)), int(D.stream_key(0x0123456789ABCDEF, 7))) == \
+        (1753845952, 3861431939, 1429204582)
+    assert D.drop_thr(0.1) == 6554 and D.drop_thr(0.25) == 16384
+    assert abs(D.keep_scale(0.1) - 65536.0 / (65536 - 6554)) < 1e-6
+    assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 0, 1, 1, 0, 1, 1, 1], [1, 1, 1, 0, 1, 1, 1, 0],
+                                                              [1, 1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 0, 1]]
+    assert D.keep_attention(42, 1, 2, 3, 6, 0.5).astype(int).tolist() == \
+        [[[[0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 1, 0], [1, 0, 1, 0, 1, 0]], [[0, 0, 1, 0, 1, 0], [1, 0, 0, 1, 0, 1], [1, 1, 1, 1, 1, 0]]]]
+    assert D.site_seed(0xC0FFEE, 3, 204) == 17806544269414322833
+    assert D.site_id("decoder.layers.3.encoder_attn") == 403 and D.w2v_site_id("encoder.layers.11.attention_output") == 211
+    m = D.keep_flat(7, 600, 768, 0.1)
+    n = m.size
+    assert abs(m.mean() - (1 - 6554 / 65536)) < 4 * (0.3 / np.sqrt(n))
+    for a, b in ((m[:, :-1], m[:, 1:]), (m[:-1], m[1:]), (m[:, :-2], m[:, 2:])):
+        assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 5 / np.sqrt(n)
+    att = D.keep_attention(11, 2, 4, 96, 160, 0.1).reshape(8, -1).astype(float)
+    c = np.corrcoef(att)
+    assert np.abs(c - np.eye(8)).max() < 5 / np.sqrt(att.shape[1])      # streams (batch, head)
+    s0 = D.keep_flat(D.site_seed(5, 0, 100), 300, 256, 0.1).ravel().astype(float)
+    s1 = D.keep_flat(D.site_seed(5, 1, 100), 300, 256, 0.1).ravel().astype(float)
+    s2 = D.keep_flat(D.site_seed(5, 0, 101), 300, 256, 0.1).ravel().astype(float)
+    assert abs(np.corrcoef(s0, s1)[0, 1]) < 5 / np.sqrt(s0.size) and abs(np.corrcoef(s0, s2)[0, 1]) < 5 / np.sqrt(s0.size)
