@@ -330,12 +330,13 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_resid", [False, True])
-def test_dropout_kernel_matches_host_generator(dev, dtype, with_resid):
+@pytest.mark.parametrize("cols", [768, 770])  # 16-byte path / pair-at-a-time path
+def test_dropout_kernel_matches_host_generator(dev, dtype, with_resid, cols):
     """tmi_dropout against the generator restated in oracle/dropout.py: same mask bit for bit, kept values
     scaled by 65536/(65536-thr), residual added in fp32 (W:205 / W:342 / W:411 sites and their backward)."""
     from oracle import dropout as DO
     ops = _ops()
-    rows, cols, p, seed = 301, 768, 0.1, 0xFEEDFACE12345
+    rows, p, seed = 301, 0.1, 0xFEEDFACE12345
     x = rnd((rows, cols + 8), dtype, dev, 90)[:, :cols]      # row stride != cols
     resid = rnd((rows, cols), dtype, dev, 91) if with_resid else None
     out = torch.empty((rows, cols), dtype=dtype, device=dev)
