@@ -92,6 +92,9 @@ def make_train_step(strategy, model, optimizer, example_inputs, warmup=2):
         eager(example_inputs)
     if strategy.world != 1 or model.device.type != "cuda" or os.environ.get("TMI_HIP_GRAPH", "0") != "1":
         return eager
+    if model._drop_p > 0.0 or model._drop_attn_p > 0.0 or model._drop_act_p > 0.0:
+        # the dropout seeds are kernel arguments chosen per step on the host: a captured graph would replay one mask
+        return eager
     try:
         return GraphedTrainStep(strategy, model, optimizer, example_inputs)
     except Exception as e:  # capture is an optimisation: report and carry on eagerly
