@@ -36,10 +36,10 @@ def test_small_ref_full_size_properties(dev):
     ga = model.arena.g.clone()
     lb = float(model.forward_backward(feats[4:].contiguous(), labels[4:].contiguous()).item())
     gb = model.arena.g.clone()
-    assert abs(0.5 * (la + lb) - loss8) <= 2e-3 * abs(loss8)
+    assert abs(0.5 * (la + lb) - loss8) <= 1e-4 * abs(loss8)   # measured 4e-7 .. 6e-6
     half = 0.5 * (ga + gb)
     rel = float((half - g8).norm() / g8.norm())
-    assert rel <= 2e-2, rel
+    assert rel <= 5e-3, rel                                     # measured 8e-4 (bf16 rounding of different batch shapes)
 
 
 def test_wav2vec2_base_full_size_properties(dev):
