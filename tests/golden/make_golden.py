@@ -30,6 +30,19 @@ def tiny_curve(steps, seed=1234, dtype=torch.float64):
             "lr": 1e-4, "oracle_dtype": str(dtype), "losses": losses, "oracle_seconds": time.time() - t0}
 
 
+def small_ref_curve(steps=10, batch=8, seed=1234, dtype=torch.float64):
+    """BASELINE.json's headline model at its headline batch: Whisper small-ref (768/12h/3072/4+4, W:13-18), B = 8, the
+    bench.py pool (seed 1234), Adam 1e-4 (W:901), dropout 0.  ``dataset.batch(8).repeat()`` without drop_remainder
+    (W:812-815): step 6 is the short batch (samples 48, 49).  ~1 min per step in fp64 on 8 cores, ~15 GB."""
+    cfg = O.make_config("small")
+    params = {k: v.to(dtype) for k, v in O.init_params(cfg, seed=seed, dtype=torch.float32).items()}
+    feats, labels = O.create_dummy_pool(seed=seed)
+    t0 = time.time()
+    losses, _ = O.train_steps(cfg, params, feats, labels, batch, steps, lr=1e-4)
+    return {"model": "whisper-small-ref (768/12h/3072/4+4, W:13-18,888)", "batch_size": batch, "steps": steps, "seed": seed,
+            "lr": 1e-4, "oracle_dtype": str(dtype), "losses": losses, "oracle_seconds": time.time() - t0}
+
+
 def w2v_curve(steps, model_size="base", seed=1234, dtype=torch.float64):
     from oracle import wav2vec2_oracle as V
     cfg = V.make_config(model_size)
@@ -45,12 +58,16 @@ def w2v_curve(steps, model_size="base", seed=1234, dtype=torch.float64):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny-steps", type=int, default=10)
-    ap.add_argument("--only", choices=["whisper", "w2v", "all"], default="all")
+    ap.add_argument("--only", choices=["whisper", "w2v", "small", "all"], default="all")
     a = ap.parse_args()
     torch.set_num_threads(8)
     if a.only in ("whisper", "all"):
         out = tiny_curve(a.tiny_steps)
         json.dump(out, open(os.path.join(HERE, "whisper_tiny_b2_10steps.json"), "w"), indent=1)
+        print(out)
+    if a.only in ("small", "all"):
+        out = small_ref_curve(10)
+        json.dump(out, open(os.path.join(HERE, "whisper_small_ref_b8_10steps.json"), "w"), indent=1)
         print(out)
     if a.only in ("w2v", "all"):
         out = w2v_curve(5)
