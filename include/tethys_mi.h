@@ -286,11 +286,15 @@ int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx, void* q, 
 int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G,
                int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 
-/* Contrastive loss (V:866-899) on S [B][T][T] fp32 = all-pairs <h_t, q_t'> (a tmi_gemm):
- * row (b,t) has logits [S[t][t], S[t][neg[b][0..Nn)]] / temperature and label 0;
+/* Contrastive loss (V:866-899; whisper_single.py:745-787) on S [B][T][T] fp32 = all-pairs <h_t, q_t'>
+ * (a tmi_gemm): row (b,t) has logits [S[t][t], S[t][idx[0..Nn)]] / temperature and label 0, where
+ * idx = neg + b*neg_sb + t*neg_st (element strides): V:908-937 draws one row of indices per batch row
+ * (neg [B][Nn]: neg_sb = Nn, neg_st = 0); whisper_single.py:789-839 one row per time step, shared by
+ * the batch (neg [T][Nn]: neg_sb = 0, neg_st = Nn).  Indices may repeat and may equal t.
  * row_loss[b*T+t] = logsumexp - logit_0; S is REPLACED by d(sum row_loss)/dS * grad_scale. */
-int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, float* row_loss, int64_t B, int64_t T,
-                            int64_t Nn, float temperature, float grad_scale, void* stream);
+int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, int64_t neg_sb, int64_t neg_st,
+                            float* row_loss, int64_t B, int64_t T, int64_t Nn, float temperature,
+                            float grad_scale, void* stream);
 
 /* Gradient clipping.  seg_off: int64 device array [nseg+1] of element offsets into g.
  * tmi_segment_sumsq: out[s] = sum g[seg_off[s]:seg_off[s+1]]^2.

@@ -275,8 +275,10 @@ def encoder_layer(p, prefix, x, cfg):
     return x + _drop(h, cfg.hidden_dropout, f"{prefix}.output")  # V:396
 
 
-def quantizer(p, hidden, cfg, force_idx=None):
+def quantizer(p, hidden, cfg, force_idx=None, clip_probs=True):
     """V:581-667 -> (quantized [B,T,cd], indices [B,T,G], perplexity, distances).
+    ``clip_probs=False`` is the older form of speech_jobs/whisper_single.py:577-579 (no clip_by_value of the
+    mean one-hots before the log).
     ``force_idx`` (tests of the bf16 path only) replaces the argmin by given code indices, so
     that a near-tie resolved differently under bf16 rounding does not mask everything else."""
     B, T, _ = hidden.shape
@@ -295,7 +297,9 @@ def quantizer(p, hidden, cfg, force_idx=None):
         quant.append(enc @ cv)  # V:638: gradient reaches the codebook only
         idxs.append(idx)
         probs.append(enc.mean(dim=(0, 1)))
-    avg = torch.stack(probs).clamp(1e-10, 1.0)  # V:653-657
+    avg = torch.stack(probs)
+    if clip_probs:
+        avg = avg.clamp(1e-10, 1.0)  # V:653-657
     perplexity = torch.exp(-(avg * torch.log(avg + 1e-10)).sum(-1)).mean()
     return torch.cat(quant, dim=-1), torch.stack(idxs, dim=-1), perplexity, torch.stack(dists, dim=2)
 
@@ -307,14 +311,14 @@ def projection_head(p, name, x, cfg):
     return _drop(h, cfg.hidden_dropout, name)  # V:560
 
 
-def forward(p, audio, cfg, force_idx=None):
+def forward(p, audio, cfg, force_idx=None, clip_probs=True):
     """V:768-825 + V:841-863 with training=True -> dict."""
     dtype = p["feature_projection.kernel"].dtype
     feats = feature_extractor(p, audio.to(dtype), cfg)
     h = dense(feats, p["feature_projection.kernel"], p["feature_projection.bias"])
     h = layer_norm(h, p["feature_projection_layer_norm.gamma"], p["feature_projection_layer_norm.beta"], cfg.layer_norm_eps)
     h = _drop(h, cfg.hidden_dropout, "feature_projection")  # V:779
-    quantized, idx, perplexity, dists = quantizer(p, h, cfg, force_idx)  # on the projected features (V:784)
+    quantized, idx, perplexity, dists = quantizer(p, h, cfg, force_idx, clip_probs)  # on the projected features (V:784)
     x = h
     for i in range(cfg.num_hidden_layers):
         x = encoder_layer(p, f"encoder.layers.{i}", x, cfg)
@@ -325,10 +329,16 @@ def forward(p, audio, cfg, force_idx=None):
 
 
 def contrastive_loss(h, q, neg_idx, temperature):
-    """V:866-899.  h, q [B,T,D]; neg_idx [B, num_negatives] (same indices for every t)."""
+    """V:866-899.  h, q [B,T,D]; neg_idx [B, num_negatives] (V: the same indices for every t) or
+    [B, T, num_negatives] (whisper_single.py:745-839: a row of indices per time step)."""
     pos = (h * q).sum(-1) / temperature
-    neg_q = q[torch.arange(q.shape[0])[:, None], neg_idx.long()]  # [B, N, D]
-    neg = torch.einsum("btd,bnd->btn", h, neg_q) / temperature
+    if neg_idx.dim() == 3:
+        B = q.shape[0]
+        neg_q = q[torch.arange(B)[:, None, None], neg_idx.long()]  # [B, T, N, D]  (tf.gather batch_dims=1)
+        neg = (h.unsqueeze(2) * neg_q).sum(-1) / temperature
+    else:
+        neg_q = q[torch.arange(q.shape[0])[:, None], neg_idx.long()]  # [B, N, D]
+        neg = torch.einsum("btd,bnd->btn", h, neg_q) / temperature
     logits = torch.cat([pos.unsqueeze(-1), neg], dim=-1)
     loss = F.cross_entropy(logits.reshape(-1, logits.shape[-1]),
                            torch.zeros(logits.shape[0] * logits.shape[1], dtype=torch.long), reduction="mean")
@@ -396,4 +406,65 @@ def train_steps(cfg, params, pool, batch_size, num_steps, seed=1234, n_replicas=
         agg = clip_by_norm_each(agg, 1.0)  # Keras clipnorm after aggregation
         adam_step(params, agg, state, lr=lr)
         losses.append(tot)
+    return losses, state
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config #1 as the file is named: speech_jobs/whisper_single.py ("S:") is a single-device
+# Wav2Vec2-base pre-training job.  Same model as V: base; what differs on the step:
+#   S:1094-1111  5 s clips (80000 samples -> T = 250), dataset.batch(B).repeat() WITHOUT drop_remainder
+#   S:789-839    negatives: a shuffle of range(T) (tf.random.shuffle(seed=42)), rolled by t + 1 for time step
+#                t, first num_negatives columns -> a different row of indices for every t
+#   S:577-579    perplexity without the clip_by_value of V:653
+#   S:1143-1180  loss = contrastive + 0.1 * (-perplexity); no NaN guard, no / replicas, no clipping
+#   S:1189       Adam(3e-5), default epsilon 1e-7, no clipnorm
+# --------------------------------------------------------------------------------------
+def sample_negative_indices_roll(rng: np.random.Generator, T: int, num_negatives: int = 100) -> np.ndarray:
+    """S:789-839 -> [T, num_negatives] int32: row t = roll(perm, t + 1)[:num_negatives], perm a shuffle of
+    range(T), the same for every batch row.  TF's shuffle stream (op seed 42, global seed unset) cannot be
+    reproduced here; the permutation comes from ``rng`` and is an input of the step, like V:'s indices."""
+    perm = rng.permutation(T).astype(np.int32)
+    n = min(num_negatives, T)  # shift[:, :num_negatives] of a T-wide tensor
+    return np.stack([np.roll(perm, t + 1)[:n] for t in range(T)])
+
+
+def step_loss_single(p, audio, neg_idx_t, cfg, force_idx=None):
+    """S:1143-1175.  ``neg_idx_t`` [T, N] (tiled over the batch, S:803)."""
+    out = forward(p, audio, cfg, force_idx, clip_probs=False)
+    B = audio.shape[0]
+    neg = neg_idx_t[None].expand(B, -1, -1)
+    _, cl = contrastive_loss(out["projected_states"], out["projected_quantized_features"], neg,
+                             cfg.contrastive_logits_temperature)
+    return cl + cfg.diversity_loss_weight * (-out["codevector_perplexity"]), out
+
+
+def loss_and_grads_single(p, audio, neg_idx_t, cfg, force_idx=None):
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    loss, out = step_loss_single(leaves, audio, neg_idx_t, cfg, force_idx)
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return loss.detach(), grads, out
+
+
+def batches_keep_remainder(pool: np.ndarray, batch: int):
+    """S:1111: dataset.batch(batch_size).repeat() - the last batch of a pass over the 50 clips is short."""
+    n = pool.shape[0]
+    while True:
+        for s_ in range(0, n, batch):
+            yield pool[s_:s_ + batch]
+
+
+def train_steps_single(cfg, params, pool, batch_size, num_steps, seed=42, lr=3e-5):
+    """S:1183-1263 loop with S:1143-1180's step: one permutation draw per step, Adam eps 1e-7, nothing clipped."""
+    rng = np.random.default_rng(seed)
+    T = feature_lengths(cfg, pool.shape[1])[-1]
+    it = batches_keep_remainder(pool, batch_size)
+    state = AdamState()
+    losses = []
+    for _ in range(num_steps):
+        a = next(it)
+        neg = torch.from_numpy(sample_negative_indices_roll(rng, T, cfg.num_negatives))
+        loss, g, _ = loss_and_grads_single(params, torch.from_numpy(a), neg, cfg)
+        adam_step(params, g, state, lr=lr, eps=1e-7)
+        losses.append(float(loss))
     return losses, state

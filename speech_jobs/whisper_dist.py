@@ -19,7 +19,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def main(argv=None):
+def main(argv=None, model_overrides=None, train_kw=None):
+    """``model_overrides`` / ``train_kw`` are for tests (tiny dimensions, short clips); the command line has neither."""
     parser = argparse.ArgumentParser(description="Whisper-small Distributed Speech Recognition")
     parser.add_argument("--num_batches", type=int, default=40, help="num_batches per replica, default is set 40")
     parser.add_argument("--batch_size", type=int, default=1, help="batch size per replica, default is set 1")
@@ -37,11 +38,15 @@ def main(argv=None):
     from tethys_speech_amd import dist as D
     from tethys_speech_amd import train
 
-    task_type, task_index, rank, world = D.task_from_env()
+    _, _, rank, world = D.task_from_env()
+    # the result-file name uses the raw TF_CONFIG task fields, as W:1037-1040 does: without TF_CONFIG they are None
+    import json
+    task_config = json.loads(os.environ.get("TF_CONFIG") or "{}").get("task", {})
+    task_type, task_index = task_config.get("type"), task_config.get("index")
     local_rank = int(os.environ.get("LOCAL_RANK", rank % max(1, torch.cuda.device_count())))
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    strategy = D.DataParallelStrategy(rank, world)
+    strategy = D.DataParallelStrategy(rank, world, backend=os.environ.get("TETHYS_DIST_BACKEND"))
 
     workspace = os.environ.get("TETHYS_WORKSPACE", "/workspace")
     result_root = os.environ.get("TETHYS_RESULT", "/result")
@@ -53,13 +58,18 @@ def main(argv=None):
         path = os.path.join(workspace, helper)
         if os.path.exists(path):
             os.system(f"sh {path} &")
+    print('''
+========================
+network profile started!
+========================''')
 
     start_time = time.time()
     model = train.train_whisper(strategy, model_type=args.model_type, batch_size=args.batch_size,
                                 num_batches=args.num_batches, precision=args.precision, device=device,
                                 checkpoint_dir=os.path.join(workspace, "checkpoints"),
                                 tensor_log_dir=args.tensor_logs, resume_from=args.resume_from,
-                                dropout=None if args.dropout is None else args.dropout == "reference")
+                                dropout=None if args.dropout is None else args.dropout == "reference",
+                                model_overrides=model_overrides, **(train_kw or {}))
     jct = time.time() - start_time
     print("Training completed.")
     print("jct:", jct)
@@ -74,6 +84,12 @@ def main(argv=None):
     elif workspace == "/workspace":
         # W:1016 has no guard: a missing model.txt is an uncaught exception -> non-zero exit
         raise FileNotFoundError(model_txt)
+    # W:1024-1026: model.save_weights(CACHE_DIR/whisper_small_model)
+    model_path = os.path.join(workspace, "model_cache", "whisper_small_model")
+    if rank == 0:
+        os.makedirs(os.path.dirname(model_path), exist_ok=True)
+        train.save_weights(model, model_path)
+    print(f"모델이 {model_path}에 저장되었습니다.")
     return 0
 
 

@@ -55,10 +55,24 @@ def w2v_curve(steps, model_size="base", seed=1234, dtype=torch.float64):
             "oracle_seconds": time.time() - t0}
 
 
+def single_curve(steps=10, seed=1234, dtype=torch.float64):
+    """BASELINE configs[0] read as the file is named (speech_jobs/whisper_single.py = single-device Wav2Vec2-base):
+    batch 2, 10 steps, 5 s clips, Adam 3e-5 / eps 1e-7, roll negatives from default_rng(42)."""
+    from oracle import wav2vec2_oracle as V
+    cfg = V.make_config("base")
+    params = {k: v.to(dtype) for k, v in V.init_params(cfg, seed=seed, dtype=torch.float32).items()}
+    pool = V.create_dummy_pool(seed=seed, length=80000)
+    t0 = time.time()
+    losses, _ = V.train_steps_single(cfg, params, pool, 2, steps, seed=42, lr=3e-5)
+    return {"model": "wav2vec2-base pretraining as speech_jobs/whisper_single.py runs it (S:), 5 s clips", "batch_size": 2,
+            "steps": steps, "seed": seed, "neg_seed": 42, "lr": 3e-5, "oracle_dtype": str(dtype), "losses": losses,
+            "oracle_seconds": time.time() - t0}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny-steps", type=int, default=10)
-    ap.add_argument("--only", choices=["whisper", "w2v", "small", "all"], default="all")
+    ap.add_argument("--only", choices=["whisper", "w2v", "small", "single", "all"], default="all")
     a = ap.parse_args()
     torch.set_num_threads(8)
     if a.only in ("whisper", "all"):
@@ -68,6 +82,10 @@ if __name__ == "__main__":
     if a.only in ("small", "all"):
         out = small_ref_curve(10)
         json.dump(out, open(os.path.join(HERE, "whisper_small_ref_b8_10steps.json"), "w"), indent=1)
+        print(out)
+    if a.only in ("single", "all"):
+        out = single_curve(10)
+        json.dump(out, open(os.path.join(HERE, "whisper_single_w2v_base_b2_10steps.json"), "w"), indent=1)
         print(out)
     if a.only in ("w2v", "all"):
         out = w2v_curve(5)

@@ -182,3 +182,82 @@ def test_two_rank_gloo_allreduce_equals_single_process_sum():
     ref = torch.cat([(ga[k] + gb[k]).reshape(-1) for k in names]).numpy()
     assert np.allclose(g0, ref, rtol=1e-12, atol=1e-15)
     assert l0 == pytest.approx(float(la) + float(lb), rel=1e-12)
+
+
+def test_rendezvous_from_tf_config():
+    """the rendezvous address comes from the cluster spec (rank 0's host:port) unless MASTER_* is set."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    tfc = '{"cluster":{"chief":["whisper-chief-0.ns.svc:2222"],"worker":["whisper-worker-0.ns.svc:2222"]},"task":{"type":"worker","index":0}}'
+    assert D.rendezvous_from_env({"TF_CONFIG": tfc}) == ("whisper-chief-0.ns.svc", "2222")
+    assert D.rendezvous_from_env({"TF_CONFIG": tfc, "MASTER_ADDR": "10.0.0.5"}) == ("10.0.0.5", "2222")
+    assert D.rendezvous_from_env({"TF_CONFIG": tfc, "MASTER_ADDR": "10.0.0.5", "MASTER_PORT": "1"}) == ("10.0.0.5", "1")
+    tfw = '{"cluster":{"worker":["w0:7000","w1:7000"]},"task":{"type":"worker","index":1}}'
+    assert D.rendezvous_from_env({"TF_CONFIG": tfw}) == ("w0", "7000")
+    assert D.rendezvous_from_env({}) == (None, None)
+
+
+_TINY = dict(d_model=32, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=64, vocab_size=128,
+             encoder_layers=2, decoder_layers=2, n_mels=8, n_ctx=12, decoder_start_token_id=127)
+
+
+def _ragged_worker(rank, world, port, q):
+    """Rank 0 has a real slice of the short final batch, rank 1 an empty one (train.py:22): both must
+    issue the same bucket collectives in the same order.  The HIP model cannot run here, so rank 0's backward is
+    played back (oracle gradients, reported in grad_ready_names() order); rank 1 runs the product's own empty-slice
+    path (report_zero_gradients)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, whisper
+    from oracle import whisper_oracle as O
+    torch.set_num_threads(2)
+    strat = D.DataParallelStrategy(rank, world, backend="gloo", bucket_bytes=4 * 2000)
+    model = whisper.create_whisper_model("small", device="cpu", precision="fp32", seed=5, **_TINY)
+    a = model.arena
+    launches = []
+    orig = strat._launch
+
+    def counting_launch():
+        if strat._pend_hi > strat._pend_lo:
+            launches.append((strat._pend_lo, strat._pend_hi))
+        orig()
+    strat._launch = counting_launch
+    strat.begin_gradients(a.g)
+    if rank == 0:
+        cfg = O.make_config("small", dropout=0.0, attention_dropout=0.0, **_TINY)
+        f, l = O.create_dummy_pool(seed=2, n_mels=8, seq_len=24, max_target_length=6, num_samples=1)
+        p = {k: v.double() for k, v in a.ref_views(a.p).items()}
+        _, g = O.loss_and_grads(p, torch.from_numpy(f), torch.from_numpy(l), cfg)
+        for k, v in a.ref_views(a.g).items():
+            v.copy_(g[k].float())
+        want = a.g.clone()
+        hi = a.numel
+        for name in model.grad_ready_names():
+            lo = a.offsets[name]
+            if lo < hi:
+                strat.gradients_ready(lo, hi)
+                hi = lo
+    else:
+        want = None
+        model.report_zero_gradients(strat.gradients_ready)
+    strat.all_reduce_gradients(a.g)
+    q.put((rank, launches, a.g.numpy().copy(), None if want is None else want.numpy()))
+    dist.destroy_process_group()
+
+
+def test_empty_slice_replica_issues_the_same_collectives():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, l0, g0, want), (_, l1, g1, _) = res
+    assert l0 == l1 and len(l0) >= 3          # same buckets, same order, more than one of them
+    assert l0[0][1] > l0[-1][1] and l0[-1][0] == 0
+    assert np.array_equal(g0, g1) and np.array_equal(g0, want)  # zeros + rank 0's gradients

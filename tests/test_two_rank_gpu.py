@@ -92,3 +92,69 @@ def test_two_rank_step_equals_accumulated_single_process(dev):
     assert np.allclose(l0, ref_losses, rtol=1e-5, atol=1e-6), (l0, ref_losses)
     err = np.abs(p0 - ref).max() / np.abs(ref).max()
     assert err <= 1e-5, err
+
+
+def _ragged_worker(rank, port, q):
+    """Step 1 is the short final batch of a pass (W:812-815 has no drop_remainder): rank 0 gets one sample,
+    rank 1 none.  ADVICE r1 (train.py:22): the empty replica must issue the same bucket collectives."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train, whisper
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=256 * 1024)
+    model = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=11, **KW)
+    strat.broadcast_parameters(model.arena.p)
+    opt = optim.Adam(1e-3)
+    b = _batches()
+    losses = []
+    for s in range(STEPS):
+        f, l = b[rank][s]
+        if s == 1:
+            f, l = (f[:1], l[:1]) if rank == 0 else (f[:0], l[:0])
+        out = train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)), opt)
+        losses.append(float(out.item()))
+    torch.cuda.synchronize()
+    q.put((rank, model.arena.p.cpu().numpy(), losses))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_ragged_final_batch_with_an_empty_replica(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ragged_worker, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, p0, l0), (_, p1, l1) = res
+    assert np.array_equal(p0, p1) and l0 == l1
+
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import optim, whisper
+    model = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=11, **KW)
+    opt = optim.Adam(1e-3)
+    b = _batches()
+    ref_losses = []
+    for s in range(STEPS):
+        tot = torch.zeros_like(model.arena.g)
+        lsum = 0.0
+        for r in range(2):
+            f, l = b[r][s]
+            if s == 1:
+                if r == 1:
+                    continue
+                f, l = f[:1], l[:1]
+            loss = model.forward_backward(torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev))
+            tot += model.arena.g
+            lsum += float(loss.item())
+        model.arena.g.copy_(tot)
+        opt.apply_gradients(model)
+        ref_losses.append(lsum)
+    assert np.allclose(l0, ref_losses, rtol=1e-5, atol=1e-6), (l0, ref_losses)
+    ref = model.arena.p.cpu().numpy()
+    assert np.abs(p0 - ref).max() / np.abs(ref).max() <= 1e-5

@@ -353,3 +353,86 @@ def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
         assert max(rel[:2]) <= 0.03 and max(rel) <= 0.35 and all(np.isfinite(got)), (rel, got, gold["losses"])
     else:
         assert max(rel) <= tol, (rel, got, gold["losses"])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE config #1 read as the file is named: speech_jobs/whisper_single.py (S:) = single-device Wav2Vec2-base,
+# roll-based negatives (S:789-839), no clip, no / replicas, Adam eps 1e-7, 5 s clips, batch() without drop_remainder
+# ---------------------------------------------------------------------------------------------------------
+def test_contrastive_with_one_index_row_per_time_step(dev):
+    """S:745-787 with S:789-839's indices: row t of neg [T, N] = roll(perm, t + 1)[:N], shared by the batch."""
+    ops = _ops()
+    B, T, D, Nn = 3, 50, 64, 20
+    hh = rnd((B, T, D), torch.float32, dev, 33, 0.3)
+    qq = rnd((B, T, D), torch.float32, dev, 34, 0.3)
+    neg_t = V.sample_negative_indices_roll(np.random.default_rng(1), T, Nn)
+    assert neg_t.shape == (T, Nn)
+    for t in (0, 7, T - 1):  # row t really is the permutation rolled by t + 1
+        full = np.roll(np.random.default_rng(1).permutation(T).astype(np.int32), t + 1)
+        assert np.array_equal(neg_t[t], full[:Nn])
+    S = torch.einsum("btd,bsd->bts", hh, qq).contiguous()
+    hr, qr = hh.double().cpu().requires_grad_(True), qq.double().cpu().requires_grad_(True)
+    _, loss = V.contrastive_loss(hr, qr, torch.from_numpy(neg_t)[None].expand(B, -1, -1), 0.1)
+    loss.backward()
+    row_loss = torch.empty(B * T, dtype=torch.float32, device=dev)
+    ops.contrastive_fwd_bwd(S, torch.from_numpy(neg_t).to(dev), row_loss, B, T, Nn, 0.1, 1.0 / (B * T), per_time=True)
+    torch.cuda.synchronize()
+    assert abs(float(row_loss.double().mean()) - float(loss)) <= 1e-4 * abs(float(loss))
+    dh = torch.einsum("bts,bsd->btd", S.double().cpu(), qq.double().cpu())
+    dqq = torch.einsum("bts,btd->bsd", S.double().cpu(), hh.double().cpu())
+    assert rel_err(dh, hr.grad) <= 1e-4 and rel_err(dqq, qr.grad) <= 1e-4
+
+
+def test_whisper_single_step_curve_fp32(dev):
+    """S:1143-1180 over 6 steps, pool of 5 clips in batches of 2 (2, 2, 1, 2, 2, 1: batch() keeps the remainder),
+    against oracle.train_steps_single in fp64."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import optim, train
+    model, ocfg, params = build("fp32", dev)
+    B, T_in = 2, 400
+    pool = V.create_dummy_pool(seed=3, num_samples=5, length=T_in)
+    ref_losses, _ = V.train_steps_single(ocfg, params, pool, B, 6, seed=42, lr=1e-3)
+    T = V.feature_lengths(ocfg, T_in)[-1]
+    rng = np.random.default_rng(42)
+    it = V.batches_keep_remainder(pool, B)
+    opt = optim.Adam(learning_rate=1e-3)  # Keras default epsilon 1e-7 (S:1189)
+    got, sizes = [], []
+    for _ in range(6):
+        a = next(it)
+        sizes.append(len(a))
+        neg = V.sample_negative_indices_roll(rng, T, ocfg.num_negatives)
+        loss = train.single_train_step(model, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                       torch.from_numpy(neg).to(dev), opt)
+        got.append(float(loss.item()))
+    assert sizes == [2, 2, 1, 2, 2, 1]
+    assert max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, ref_losses)) <= 2e-4, (got, ref_losses)
+
+
+def test_whisper_single_base_golden_fp32(dev):
+    """BASELINE configs[0] as named: Wav2Vec2-base, batch 2, 10 steps, 5 s clips (T = 250), against the committed
+    fp64-oracle curve (tests/golden/make_golden.py --only single).  fp32 path, relative 2e-3 (loss is O(400))."""
+    import json, os
+    path = os.path.join(os.path.dirname(__file__), "golden", "whisper_single_w2v_base_b2_10steps.json")
+    if not os.path.exists(path):
+        pytest.skip("golden curve not generated")
+    gold = json.load(open(path))
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import optim, train, wav2vec2
+    ocfg = V.make_config("base")
+    params = V.init_params(ocfg, seed=gold["seed"], dtype=torch.float32)
+    model = wav2vec2.create_full_model("pretraining", "base", device=dev, precision="fp32")
+    model.arena.load_ref(params)
+    model.refresh_shadows()
+    pool = V.create_dummy_pool(seed=gold["seed"], length=80000)
+    rng = np.random.default_rng(gold["neg_seed"])
+    it = V.batches_keep_remainder(pool, 2)
+    opt = optim.Adam(learning_rate=gold["lr"])
+    got = []
+    for _ in range(len(gold["losses"])):
+        a = next(it)
+        neg = V.sample_negative_indices_roll(rng, 250, ocfg.num_negatives)
+        loss = train.single_train_step(model, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                       torch.from_numpy(neg).to(dev), opt)
+        got.append(float(loss.item()))
+    rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
+    assert max(rel) <= 2e-3, (rel, got, gold["losses"])

@@ -189,3 +189,40 @@ def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
         got.append(float(loss.item()))
     err = max(abs(a - b) for a, b in zip(got, gold["losses"]))
     assert err <= tol, (err, got, gold["losses"])
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
+    """BASELINE.json's headline model at its headline batch (configs[1]): Whisper small-ref (768/12h/3072/4+4,
+    W:13-18), per-GPU batch 8, 30 s clips, Adam 1e-4 (W:901), dropout 0, the bench.py pool (seed 1234), 10 steps
+    against the committed fp64-oracle curve.  This is the north-star's "loss curve matching to 1e-3" on the model
+    it names: the fp32 path holds 1e-3 absolute per step; bf16 is the perf mode and is held to 2e-2, reported
+    separately.  ``dataset.batch(8).repeat()`` keeps the remainder (W:812-815): step 6 is the
+    two-sample batch."""
+    path = os.path.join(GOLD, "whisper_small_ref_b8_10steps.json")
+    if not os.path.exists(path):
+        pytest.skip("golden curve not generated")
+    gold = json.load(open(path))
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import whisper, optim, dist, train
+    ocfg = O.make_config("small")
+    params = O.init_params(ocfg, seed=gold["seed"], dtype=torch.float32)
+    model = whisper.create_whisper_model("small", device=dev, precision=precision)
+    assert model.arena.n_params == 147_781_632
+    model.arena.load_ref(params)
+    model.refresh_shadows()
+    feats, labels = O.create_dummy_pool(seed=gold["seed"])
+    opt = optim.Adam(learning_rate=gold["lr"])
+    strat = dist.DataParallelStrategy(0, 1)
+    it = O.batches(feats, labels, gold["batch_size"])
+    got, sizes = [], []
+    for _ in range(len(gold["losses"])):
+        f, l = next(it)
+        sizes.append(len(f))
+        loss = train.distributed_train_step(strat, model, (torch.from_numpy(np.ascontiguousarray(f)).to(dev),
+                                                           torch.from_numpy(np.ascontiguousarray(l)).to(dev)), opt)
+        got.append(float(loss.item()))
+    assert sizes == [8, 8, 8, 8, 8, 8, 2, 8, 8, 8]
+    err = [abs(a - b) for a, b in zip(got, gold["losses"])]
+    print(f"small-ref B=8 {precision}: max |dloss| = {max(err):.2e} (bound {tol:g}); per step {['%.1e' % e for e in err]}")
+    assert max(err) <= tol, (err, got, gold["losses"])

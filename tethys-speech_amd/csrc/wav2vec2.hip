@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const int32_t* __restrict__
 // S [B][T][T] fp32 = <h_t, q_t'> (all pairs).  Row (b,t): logits = [S[t][t], S[t][neg[b][n]]...] / temp,
 // loss = logsumexp - logit0; S row is replaced by dloss/dS (scaled by grad_scale).
 __global__ __launch_bounds__(128) void contrastive_kernel(float* __restrict__ S, const int32_t* __restrict__ neg,
+                                                          int64_t neg_sb, int64_t neg_st,
                                                           float* __restrict__ row_loss, int Tn, int Nn,
                                                           float inv_temp, float grad_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(128) void contrastive_kernel(float* __restrict__ S,
   const int64_t row = blockIdx.x;
   const int b = (int)(row / Tn), t = (int)(row % Tn);
   float* Sr = S + row * Tn;
-  const int32_t* nb = neg + (int64_t)b * Nn;
+  const int32_t* nb = neg + (int64_t)b * neg_sb + (int64_t)t * neg_st;
   for (int i = threadIdx.x; i < Tn; i += 128) acc[i] = 0.f;
   for (int i = threadIdx.x; i <= Nn; i += 128) lg[i] = (i == 0 ? Sr[t] : Sr[nb[i - 1]]) * inv_temp;
   __syncthreads();
@@ -638,15 +639,17 @@ extern "C" int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, 
   return tmi_check_launch("tmi_vq_bwd");
 }
 
-extern "C" int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, float* row_loss, int64_t B, int64_t T, int64_t Nn,
-                                       float temperature, float grad_scale, void* stream) {
-  if (!S || !neg || !row_loss || B <= 0 || T <= 0 || Nn < 0 || T > 8192 || Nn > 4096 || temperature <= 0.f) {
+extern "C" int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, int64_t neg_sb, int64_t neg_st, float* row_loss,
+                                       int64_t B, int64_t T, int64_t Nn, float temperature, float grad_scale,
+                                       void* stream) {
+  if (!S || !neg || !row_loss || B <= 0 || T <= 0 || Nn < 0 || T > 8192 || Nn > 4096 || temperature <= 0.f ||
+      neg_sb < 0 || neg_st < 0) {
     tmi_set_error("tmi_contrastive_fwd_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
   const size_t lds = (size_t)(T + Nn + 1) * sizeof(float);
   hipLaunchKernelGGL(contrastive_kernel, dim3((unsigned)(B * T)), dim3(128), lds, reinterpret_cast<hipStream_t>(stream),
-                     S, neg, row_loss, (int)T, (int)Nn, 1.0f / temperature, grad_scale);
+                     S, neg, neg_sb, neg_st, row_loss, (int)T, (int)Nn, 1.0f / temperature, grad_scale);
   return tmi_check_launch("tmi_contrastive_fwd_bwd");
 }
 

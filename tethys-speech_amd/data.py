@@ -69,12 +69,17 @@ class W2VDummyDataset:
     ``batch(global_batch, drop_remainder=True).repeat()``; replica r takes rows
     [r*B, (r+1)*B) of every global batch.  The pool is uploaded once."""
 
-    def __init__(self, batch_size, length=32000, device="cuda:0", rank=0, world=1, seed=1234, num_samples=50):
+    def __init__(self, batch_size, length=32000, device="cuda:0", rank=0, world=1, seed=1234, num_samples=50,
+                 drop_remainder=True):
+        """``drop_remainder=False`` (single replica only) is speech_jobs/whisper_single.py:1111's
+        ``dataset.batch(batch_size).repeat()``: the last batch of a pass is short."""
         pool = np.random.default_rng(seed).standard_normal((num_samples, length)).astype(np.float32)
         self.audio = torch.from_numpy(pool).to(device)
         self.batch_size, self.rank, self.world = batch_size, rank, world
         self.global_batch = batch_size * world
-        self.n = num_samples // self.global_batch * self.global_batch
+        if not drop_remainder and world != 1:
+            raise ValueError("the keep-remainder form is the single-device job's")
+        self.n = num_samples // self.global_batch * self.global_batch if drop_remainder else num_samples
         if self.n == 0:
             raise ValueError("global batch larger than the 50-clip pool")
         self._pos = 0
@@ -87,4 +92,4 @@ class W2VDummyDataset:
             self._pos = 0
         s = self._pos + self.rank * self.batch_size
         self._pos += self.global_batch
-        return self.audio[s:s + self.batch_size]
+        return self.audio[s:min(s + self.batch_size, self.n)]

@@ -43,6 +43,24 @@ def task_from_env(env=None) -> Tuple[str, int, int, int]:
     return task.get("type") or "worker", int(task.get("index") or 0), 0, 1
 
 
+def rendezvous_from_env(env=None) -> Tuple[Optional[str], Optional[str]]:
+    """(MASTER_ADDR, MASTER_PORT) for torch.distributed's rendezvous.  Explicit MASTER_ADDR / MASTER_PORT win;
+    otherwise, when TF_CONFIG names a cluster, rank 0's "host:port" entry (chief[0], or worker[0] without a
+    chief) — the address every pod of the reference's TFJob already knows (sample_tfjobs/*.yaml run chief and
+    worker in separate pods, so a loopback default would have each pod rendezvous with itself)."""
+    env = os.environ if env is None else env
+    addr, port = env.get("MASTER_ADDR"), env.get("MASTER_PORT")
+    cluster = json.loads(env.get("TF_CONFIG") or "{}").get("cluster", {})
+    first = (cluster.get("chief") or cluster.get("worker") or [None])[0]
+    if first:
+        host, _, p = str(first).rpartition(":")
+        if not host:  # no port in the entry
+            host, p = str(first), ""
+        addr = addr or host
+        port = port or (p if p.isdigit() else None)
+    return addr, port
+
+
 class DataParallelStrategy:
     def __init__(self, rank: int = 0, world: int = 1, backend: Optional[str] = None,
                  bucket_bytes: int = 24 << 20, init: bool = True):
@@ -57,8 +75,9 @@ class DataParallelStrategy:
         self._pend_lo = self._pend_hi = 0
         if world > 1 and init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
+            addr, port = rendezvous_from_env()
+            os.environ["MASTER_ADDR"] = addr or "127.0.0.1"
+            os.environ["MASTER_PORT"] = port or "29531"
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     @property

@@ -353,8 +353,11 @@ def vq_bwd(idx, dq, dcodebook, rows, G, Nc, gd):
           "tmi_vq_bwd")
 
 
-def contrastive_fwd_bwd(S, neg, row_loss, B, T, Nn, temperature, grad_scale):
-    check(lib().tmi_contrastive_fwd_bwd(S.data_ptr(), neg.data_ptr(), row_loss.data_ptr(), B, T, Nn, temperature,
+def contrastive_fwd_bwd(S, neg, row_loss, B, T, Nn, temperature, grad_scale, per_time=False):
+    """``neg`` [B, Nn] (one row of indices per batch row, V:908-937) or, with ``per_time``, [T, Nn] (one row per
+    time step shared by the batch, whisper_single.py:789-839)."""
+    sb, st = (0, Nn) if per_time else (Nn, 0)
+    check(lib().tmi_contrastive_fwd_bwd(S.data_ptr(), neg.data_ptr(), sb, st, row_loss.data_ptr(), B, T, Nn, temperature,
                                         grad_scale, stream()), "tmi_contrastive_fwd_bwd")
 
 

@@ -22,7 +22,8 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
     if features.shape[0] > 0:
         loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready)
     else:
-        model.arena.g.zero_()
+        # same reports as a real backward, so this rank's bucket launches match its peers' one for one
+        model.report_zero_gradients(strategy.gradients_ready)
         loss = torch.zeros(1, dtype=torch.float32, device=model.device)
     optimizer.apply_gradients(model, strategy)
     return strategy.reduce_sum(loss.clone())
@@ -54,6 +55,7 @@ class GraphedTrainStep:
         self.labels.copy_(l)
         self._set_scalars(optimizer.iterations + 1)
         torch.cuda.synchronize()
+        self._ws = model.ws  # the workspace set whose addresses the capture bakes in: keep it alive (model._ws_sets may evict it)
         self.graph = torch.cuda.CUDAGraph()
         m0 = (model.arena.p.clone(), model.arena.m.clone(), model.arena.v.clone())  # capture must not train
         with torch.cuda.graph(self.graph):
@@ -106,7 +108,7 @@ def make_train_step(strategy, model, optimizer, example_inputs, warmup=2):
 def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4, *, batch_size=1,
                   num_batches=40, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print, seed=1234,
                   model_overrides=None, seq_len=3000, max_target_length=100, tensor_log_dir=None,
-                  resume_from=None, dropout=None):
+                  resume_from=None, dropout=None, loss_fetch_depth=2):
     """W:894-958: model + Adam(1e-4), dummy dataset, per-step log line, checkpoint at epoch end.
     ``tensor_log_dir``: also write the tensor-size / skewness report of the reference's
     ``whisper_dist_tensorsize.py`` there (computed from shapes, see tensorsize.py).
@@ -122,8 +124,6 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
     if dropout:
         model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=seed * 1000003 + strategy.rank)
     optimizer = Adam(learning_rate=learning_rate)
-    if resume_from:
-        load_checkpoint(model, optimizer, resume_from)
     report = None
     if tensor_log_dir and strategy.rank == 0:
         from .tensorsize import TensorSizeReport
@@ -134,26 +134,31 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
                               max_target_length=max_target_length, device=device, rank=strategy.rank,
                               world=strategy.world, seed=seed, drop_remainder=strategy.world > 1)
     it = iter(ds)
-    step = 0
+    step = load_checkpoint(model, optimizer, resume_from, dataset=ds) if resume_from else 0
     losses = []
     start_time = time.time()
+    fetch = LossFetcher(device, depth=loss_fetch_depth)
+
+    def emit(final):
+        for lv, (i, t0) in final:
+            losses.append(lv)
+            log(_step_line(i, lv, start_time, t0, time.time()))
+            if report is not None:
+                report.log_step(i)
     for epoch in range(num_epochs):
         log(f"Epoch {epoch + 1}/{num_epochs}")
         for _ in range(num_batches):
             inputs = next(it)
             step_start = time.time()
             loss = distributed_train_step(strategy, model, inputs, optimizer)
-            lv = float(loss.item())  # the reference's loss.numpy() host sync (W:951)
-            step_end = time.time()
-            losses.append(lv)
-            log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
-                f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
-            if report is not None:
-                report.log_step(step)
+            # the reference's loss.numpy() (W:951), fetched behind an event so the next step is enqueued meanwhile
+            emit(fetch.push(loss, (step, step_start)))
             step += 1
+        emit(fetch.drain())
         if checkpoint_dir and strategy.rank == 0:
             os.makedirs(checkpoint_dir, exist_ok=True)
-            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"whisper_{model_type}_epoch_{epoch + 1}.pt"))
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"whisper_{model_type}_epoch_{epoch + 1}.pt"),
+                            dataset=ds, step=step)
     if report is not None:
         summ = report.save_final_results()
         report.close()
@@ -162,22 +167,85 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
     return model
 
 
-def save_checkpoint(model, optimizer, path):
-    """tf.train.Checkpoint(model, optimizer).save (W:919,956): flat-arena dump."""
+def save_weights(model, path):
+    """model.save_weights (W:1024-1025, V:1437-1439): the parameters only, keyed by the reference's variable paths."""
+    torch.save({k: v.detach().cpu().clone() for k, v in model.arena.ref_views(model.arena.p).items()}, path)
+
+
+class LossFetcher:
+    """The per-step ``loss.numpy()`` of the reference's log line (W:951) without stalling the launch queue: each
+    step's device scalar is copied to its own pinned slot behind an event, and the line of step i is printed once
+    its event has completed - normally while step i+1 is already being enqueued - instead of the host blocking on
+    every step.  ``depth`` = how many steps may be in flight before the oldest is waited for (1 = the reference's
+    synchronous behaviour)."""
+
+    def __init__(self, device, depth=2):
+        self.depth = max(1, int(depth))
+        self.cuda = torch.device(device).type == "cuda"
+        n = self.depth + 1
+        self.slots = [torch.zeros(1, dtype=torch.float32).pin_memory() if self.cuda else torch.zeros(1) for _ in range(n)]
+        self.events = [torch.cuda.Event() if self.cuda else None for _ in range(n)]
+        self.pending = []  # (slot, payload)
+        self._i = 0
+
+    def push(self, loss, payload):
+        """Queue ``loss`` (1-element device tensor); returns the (value, payload) pairs that became final."""
+        i = self._i
+        self._i = (self._i + 1) % len(self.slots)
+        self.slots[i].copy_(loss.detach().reshape(1), non_blocking=True)
+        if self.cuda:
+            self.events[i].record()
+        self.pending.append((i, payload))
+        out = []
+        while self.pending and (len(self.pending) >= self.depth or self._done(self.pending[0][0])):
+            out.append(self._pop())
+        return out
+
+    def _done(self, i):
+        return (not self.cuda) or self.events[i].query()
+
+    def _pop(self):
+        i, payload = self.pending.pop(0)
+        if self.cuda:
+            self.events[i].synchronize()
+        return float(self.slots[i].item()), payload
+
+    def drain(self):
+        out = []
+        while self.pending:
+            out.append(self._pop())
+        return out
+
+
+def _step_line(step, lv, start_time, step_start, step_end):
+    return (f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
+            f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
+
+
+def save_checkpoint(model, optimizer, path, dataset=None, step=None):
+    """tf.train.Checkpoint(model, optimizer).save (W:919,956): flat-arena dump, plus what a resumed run needs to
+    continue rather than replay: the dropout step counter (mask stream), the dataset cursor and the step index."""
     a = model.arena
     torch.save({"p": a.p.cpu(), "m": a.m.cpu(), "v": a.v.cpu(), "iterations": optimizer.iterations,
-                "names": a.names, "offsets": a.offsets, "shapes": a.shapes}, path)
+                "names": a.names, "offsets": a.offsets, "shapes": a.shapes,
+                "drop_step": int(getattr(model, "_drop_step", 0)),
+                "data_pos": None if dataset is None else int(dataset._pos),
+                "step": optimizer.iterations if step is None else int(step)}, path)
 
 
-def load_checkpoint(model, optimizer, path):
-    """The restore path the reference lacks."""
+def load_checkpoint(model, optimizer, path, dataset=None):
+    """The restore path the reference lacks.  Returns the step index to continue from."""
     ck = torch.load(path, map_location="cpu")
     a = model.arena
     if ck["names"] != a.names or ck["offsets"] != a.offsets or ck["shapes"] != a.shapes or ck["p"].numel() != a.p.numel():
         raise ValueError("checkpoint layout does not match the model")
     a.p.copy_(ck["p"]); a.m.copy_(ck["m"]); a.v.copy_(ck["v"])
     optimizer.iterations = int(ck["iterations"])
+    model._drop_step = int(ck.get("drop_step", optimizer.iterations))
+    if dataset is not None and ck.get("data_pos") is not None:
+        dataset._pos = int(ck["data_pos"])
     model.refresh_shadows()
+    return int(ck.get("step", optimizer.iterations))
 
 
 # ---------------------------------------------------------------------------------------
@@ -211,7 +279,8 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
 
 def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_epochs=1, learning_rate=3e-5, *,
                    batch_size=1, num_batches=5, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print,
-                   seed=1234, clip_samples=32000, model_overrides=None, dropout=None):
+                   seed=1234, clip_samples=32000, model_overrides=None, dropout=None, resume_from=None,
+                   loss_fetch_depth=2):
     """V:1263-1376: model + Adam(3e-5, eps 1e-8, clipnorm 1), 50 x 2 s dummy clips, per-step log
     line, checkpoint every 50 steps and at the end."""
     import numpy as np
@@ -231,6 +300,17 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
     rng = np.random.default_rng(seed + 1)
     it = iter(ds)
     step, losses = 0, []
+    fetch = LossFetcher(device, depth=loss_fetch_depth)
+
+    def emit(final):
+        for lv, (i, t0) in final:
+            losses.append(lv)
+            log(_step_line(i, lv, start_time, t0, time.time()))
+    if resume_from:
+        step = load_checkpoint(model, optimizer, resume_from, dataset=ds)
+        model._prepare(batch_size, clip_samples)
+        for _ in range(step):  # the negative-index stream continues where the saved run stopped
+            sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
     start_time = time.time()
     for epoch in range(num_epochs):
         log(f"Epoch {epoch + 1}/{num_epochs}")
@@ -242,17 +322,78 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             neg = torch.from_numpy(neg_all[strategy.rank * batch_size:(strategy.rank + 1) * batch_size]).to(device)
             step_start = time.time()
             loss = wav2vec2_train_step(strategy, model, audio, neg, optimizer)
-            lv = float(loss.item())
-            step_end = time.time()
-            losses.append(lv)
-            log(f"Step {step}, Loss: {lv:.4f}, Time: {time.strftime('%H:%M:%S')} "
-                f"(경과: {step_end - start_time:.2f}초, 스텝 시간: {step_end - step_start:.2f}초)")
+            emit(fetch.push(loss, (step, step_start)))
             step += 1
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
+                emit(fetch.drain())
                 os.makedirs(checkpoint_dir, exist_ok=True)
-                save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_step_{step}.pt"))
+                save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_step_{step}.pt"),
+                                dataset=ds, step=step)
+        emit(fetch.drain())
         if checkpoint_dir and strategy.rank == 0:
             os.makedirs(checkpoint_dir, exist_ok=True)
-            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_epoch_{epoch + 1}.pt"))
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_epoch_{epoch + 1}.pt"),
+                            dataset=ds, step=step)
+    model.losses = losses
+    return model
+
+
+# ---------------------------------------------------------------------------------------
+# speech_jobs/whisper_single.py ("S:") - BASELINE config #1 as the file is named: a single-device Wav2Vec2-base
+# pre-training job.  Same model as V: base; the step has no replica scaling, no clipping, Adam's
+# default epsilon, roll-based negatives and 5 s clips.
+# ---------------------------------------------------------------------------------------
+def single_train_step(model, audio, neg_indices_t, optimizer):
+    """S:1143-1180: forward, loss = contrastive + 0.1 * (-perplexity), gradients, Adam.  ``neg_indices_t`` [T, N]
+    (wav2vec2.sample_negative_indices_roll)."""
+    model.neg_per_time = True
+    loss = model.forward_backward(audio, neg_indices_t, num_replicas=1)
+    optimizer.apply_gradients(model, None)
+    model._pack_pos()
+    return loss
+
+
+def train_wav2vec2_single(model_type="pretraining", num_epochs=1, learning_rate=3e-5, *, batch_size=4, num_batches=40,
+                          precision="bf16", device="cuda:0", checkpoint_dir=None, log=print, seed=1234,
+                          clip_samples=80000, model_overrides=None, dropout=None, model_size="base", loss_fetch_depth=2):
+    """S:1183-1263: Wav2Vec2-base + Adam(3e-5) (epsilon 1e-7, no clipnorm: S:1189), 50 x 5 s dummy clips batched
+    WITHOUT drop_remainder (S:1094-1111), per-step log line, checkpoint at the end of the epoch."""
+    import numpy as np
+    from .data import W2VDummyDataset
+    from .wav2vec2 import create_full_model, sample_negative_indices_roll
+    model = create_full_model(model_type, model_size, device=device, precision=precision, seed=seed,
+                              **(model_overrides or {}))
+    model.refresh_shadows()
+    if dropout is None:
+        dropout = precision == "bf16"
+    if dropout:
+        c = model.config
+        model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=seed * 1000003, act_p=c.activation_dropout)
+    optimizer = Adam(learning_rate=learning_rate)  # Keras default epsilon 1e-7
+    ds = W2VDummyDataset(batch_size, length=clip_samples, device=device, seed=seed, drop_remainder=False)
+    rng = np.random.default_rng(42)  # the reference asks tf.random.shuffle for seed 42 (S:799)
+    it = iter(ds)
+    step, losses = 0, []
+    start_time = time.time()
+    fetch = LossFetcher(device, depth=loss_fetch_depth)
+
+    def emit(final):
+        for lv, (i, t0) in final:
+            losses.append(lv)
+            log(_step_line(i, lv, start_time, t0, time.time()))
+    for epoch in range(num_epochs):
+        log(f"Epoch {epoch + 1}/{num_epochs}")
+        for _ in range(num_batches):
+            audio = next(it)
+            model._prepare(audio.shape[0], audio.shape[1])
+            neg = torch.from_numpy(sample_negative_indices_roll(rng, model.T, model.config.num_negatives)).to(device)
+            step_start = time.time()
+            loss = single_train_step(model, audio, neg, optimizer)
+            emit(fetch.push(loss, (step, step_start)))
+            step += 1
+        emit(fetch.drain())
+        if checkpoint_dir:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"model_epoch_{epoch + 1}.pt"), dataset=ds, step=step)
     model.losses = losses
     return model

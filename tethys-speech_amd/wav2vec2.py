@@ -89,6 +89,15 @@ def sample_negative_indices(rng: np.random.Generator, batch_size: int, T: int, n
     return order[:, :num_negatives].astype(np.int32)
 
 
+def sample_negative_indices_roll(rng: np.random.Generator, T: int, num_negatives: int = 100) -> np.ndarray:
+    """speech_jobs/whisper_single.py:789-839 -> [T, min(num_negatives, T)] int32: row t = roll(perm, t + 1)[:N] with
+    perm a shuffle of range(T), shared by every batch row.  (TF's shuffle stream, op seed 42, is not reproducible
+    outside TF: the permutation is drawn from ``rng`` and is an input of the step.)"""
+    perm = rng.permutation(T).astype(np.int32)
+    n = min(num_negatives, T)
+    return np.stack([np.roll(perm, t + 1)[:n] for t in range(T)])
+
+
 class W2VArena(Arena):
     def __init__(self, cfg: Wav2Vec2Config, device):
         H, I = cfg.hidden_size, cfg.intermediate_size
@@ -150,6 +159,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self.arena = W2VArena(config, self.device)
         self.arena.init_keras_defaults(seed)
         self.ws: Dict[str, torch.Tensor] = {}
+        self._ws_sets: Dict[tuple, Dict[str, torch.Tensor]] = {}
         self._ws_key = None
         self.mirror = None
         if precision == "bf16":
@@ -189,7 +199,12 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         key = (B, T_in)
         if self._ws_key == key:
             return
-        self.ws.clear()
+        # one workspace set per batch shape, kept alive across shape changes: a captured HIP graph has the
+        # addresses of the set it was captured with baked in (a short final batch must not free them), and the
+        # zero pad rows of the conv buffers are an invariant of each set
+        self.ws = self._ws_sets.setdefault((key, self._drop_p > 0.0), {})
+        while len(self._ws_sets) > 4:  # (a holder of an evicted set, e.g. GraphedTrainStep, keeps it alive itself)
+            self._ws_sets.pop(next(k for k in self._ws_sets if self._ws_sets[k] is not self.ws))
         self._ws_key = key
         cfg = self.config
         f32 = torch.float32
@@ -299,9 +314,12 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         (contrastive + 0.1 * (-perplexity)) / num_replicas; gradients of it land in ``arena.g``."""
         cfg = self.config
         B, T_in = audio.shape
-        if audio.dtype != torch.float32 or neg_indices.dtype != torch.int32 or neg_indices.shape[0] != B:
-            raise TypeError("audio must be float32 [B, T] and neg_indices int32 [B, N]")
+        if audio.dtype != torch.float32 or neg_indices.dtype != torch.int32 or neg_indices.dim() != 2:
+            raise TypeError("audio must be float32 [B, T] and neg_indices int32 [B, N] (or [T, N] with neg_per_time)")
         self._prepare(B, T_in)
+        per_time = bool(getattr(self, "neg_per_time", False))  # whisper_single.py's negatives: one index row per time step
+        if neg_indices.shape[0] != (self.T if per_time else B):
+            raise ValueError("neg_indices must have one row per " + ("time step" if per_time else "batch row"))
         ws, a = self.ws, self.arena
         L = len(cfg.conv_dim)
         Gn = cfg.num_conv_pos_embedding_groups
@@ -401,7 +419,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         Nn = neg_indices.shape[1]
         inv_rep = 1.0 / num_replicas
         ops.contrastive_fwd_bwd(S, neg_indices, ws["row_loss"], B, T, Nn, cfg.contrastive_logits_temperature,
-                                inv_rep / R)
+                                inv_rep / R, per_time=per_time)
         ops.sum_scale(ws["row_loss"], ws["closs"], R, 1.0 / R)
         ops.loss_combine(ws["closs"], ws["perplexity"], -cfg.diversity_loss_weight, inv_rep, ws["loss"])
 

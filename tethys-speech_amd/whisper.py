@@ -188,6 +188,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         self.pe_enc_t = self.pe_enc.to(self.dtype)
         self._ws_key = None
         self.ws: Dict[str, torch.Tensor] = {}
+        self._ws_sets: Dict[tuple, Dict[str, torch.Tensor]] = {}
         # bf16 mirror of the whole parameter arena (perf mode), same flat indexing: every
         # kernel in its natural Keras [in, out] layout.  Forward reads it k-strided (hardware
         # transposed LDS reads), dgrad reads it k-contiguous.  Written by the Adam kernel itself.
@@ -208,7 +209,12 @@ class WhisperForConditionalGeneration(KernelBlocks):
         key = (B, T_in, S)
         if self._ws_key == key:
             return
-        self.ws.clear()
+        # one workspace set per batch shape, kept alive across shape changes: a captured HIP graph has the
+        # addresses of the set it was captured with baked in (a short final batch must not free them), and the
+        # zero pad rows of the conv buffers are an invariant of each set
+        self.ws = self._ws_sets.setdefault((key, self._drop_p > 0.0), {})
+        while len(self._ws_sets) > 4:  # (a holder of an evicted set, e.g. GraphedTrainStep, keeps it alive itself)
+            self._ws_sets.pop(next(k for k in self._ws_sets if self._ws_sets[k] is not self.ws))
         self._ws_key = key
         cfg = self.config
         if S > cfg.max_target_positions:
@@ -314,6 +320,33 @@ class WhisperForConditionalGeneration(KernelBlocks):
     # attention: q/k/v given as (tensor2d, column offset); rows are (b, t) with Tq / Tk per batch
 
 
+    def grad_ready_names(self) -> List[str]:
+        """The parameters at which backward reports "everything stored at or after this one is final", in the
+        order it reports them (arena order reversed).  The data-parallel strategy launches its buckets from
+        these reports, so a replica with nothing to compute (an empty slice of a short final batch) walks the
+        same list: every rank then issues the same collectives in the same order."""
+        cfg = self.config
+        names = ["decoder.layer_norm.gamma"]
+        names += [f"decoder.layers.{i}.self_attn_layer_norm.gamma" for i in reversed(range(cfg.decoder_layers))]
+        if cfg.decoder_layers:
+            names.append("decoder.cross_kv.kernel")
+        names += ["decoder.embed_tokens.embeddings", "encoder.layer_norm.gamma"]
+        names += [f"encoder.layers.{i}.self_attn_layer_norm.gamma" for i in reversed(range(cfg.encoder_layers))]
+        names.append("encoder.conv1.kernel")
+        return names
+
+    def report_zero_gradients(self, grad_ready=None):
+        """The gradient arena of a replica whose slice of the batch is empty: zeros, reported through
+        ``grad_ready`` range by range exactly as a real backward would."""
+        a = self.arena
+        a.g.zero_()
+        hi = a.numel
+        for name in self.grad_ready_names():
+            lo = a.offsets[name]
+            if grad_ready is not None and lo < hi:
+                grad_ready(lo, hi)
+                hi = lo
+
     # -- forward -------------------------------------------------------------------------
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
                          grad_ready=None):
@@ -347,9 +380,12 @@ class WhisperForConditionalGeneration(KernelBlocks):
         scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
         a.g.zero_()
         done = [a.numel]
+        expected = iter(self.grad_ready_names())
 
         def ready(name):
             """Everything stored at or after parameter ``name`` now has its final gradient."""
+            if name != next(expected, None):
+                raise RuntimeError(f"backward reported {name} out of the order grad_ready_names() promises")
             lo = a.offsets[name]
             if grad_ready is not None and lo < done[0]:
                 # (a consumer that acts on the range at once must first order itself after the
