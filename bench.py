@@ -11,19 +11,23 @@ per-GPU batch 8, 30 s clips = [8, 80, 3000] features + [8, 100] labels).  Weak s
 per-GPU batch is fixed, value = 30 s * 8 * N * K / max-over-ranks wall time.
 The step runs as the reference's does (training=True): its Dropout layers (W:29-30, rates 0.1 / 0.1) are
 active, with counter-based masks (--dropout off gives the rates-0 configuration the loss-curve parity tests pin).
+``--workload wav2vec2`` times BASELINE configs[3]'s model (Wav2Vec2-base pre-training step, 2 s clips) the same way.
 
-Also reported on the same JSON line:
+Every line carries, besides the contract's fields:
   roofline      the dominant kernel class (the MFMA GEMM, tmi_gemm): algorithmic FLOPs of
                 every tmi_gemm launch in a step / their device time measured with HIP events
                 recorded on the launch stream during an instrumented pass of the same steps
                 (weight-gradient side stream off, so launches do not overlap), against the
-                2.5 PFLOP/s dense bf16 MFMA peak.
+                2.5 PFLOP/s dense bf16 MFMA peak (157.3 TFLOP/s fp32 MFMA with --precision fp32).
   roofline_classes  the same measurement for every instrumented kernel class (GEMM and fused attention
-                against the MFMA peak by algorithmic flop; Adam, LayerNorm, bias column sums and the
-                cross-entropy against the 8 TB/s HBM peak by algorithmic bytes).
-  cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the
-                host cores, rank 0, N = 1 only, on a bounded sample (batch 2, 1 warm-up + up to
-                6 timed steps, ~14 s, of the same model and clip length; dropout rates 0).
+                against the MFMA peak by algorithmic flop — attention: forward 4·B·H·Tq·Tk·64, backward twice that,
+                SURVEY 8d; Adam, LayerNorm, GroupNorm, bias column sums and the cross-entropy against the 8 TB/s
+                HBM peak by algorithmic bytes).
+  cpu_baseline  the oracle (restated reference CPU path, TensorFlow unavailable) timed on the host cores, rank 0,
+                N = 1 only, on a bounded sample of the SAME workload (same model, per-GPU batch, clip length, seed;
+                dropout rates 0): thread setting 1 = the physical cores of one socket this process may use,
+                setting 2 = 5 threads (the reference pod's CPU limit, sample_tfjobs/whisper-dist.yaml:36); the
+                CPU's per-step losses are compared with the GPU fp32 path on the same steps.
 """
 import argparse
 import json
@@ -35,149 +39,245 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CLIP_SECONDS = 30.0
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3    # exact-fp32 MFMA = the fp32 vector rate (same guide)
 HBM_PEAK_GBS = 8000.0            # HBM3E peak (same guide; ~6.3 TB/s is what streams reach)
-GF_PER_SAMPLE_BY_SIZE = {"tiny": 141.3, "small": 449.1, "large": 8320.6}
-GF_PER_SAMPLE = 449.1           # fwd+bwd algorithmic GFLOP per 30 s sample, small-ref
-
-
-def cpu_baseline(model_type, seq_len, sample_batch=2, max_steps=6, budget_s=14.0):
-    import torch
-    from oracle import whisper_oracle as O  # checker, timed as the CPU baseline only
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, 16)  # the 1-GPU box's CPU share; more threads than share only thrash
-    torch.set_num_threads(cores)
-    cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
-    params = O.init_params(cfg, seed=1234, dtype=torch.float32)
-    feats, labels = O.create_dummy_pool(seed=1234, seq_len=seq_len, num_samples=sample_batch * (max_steps + 1))
-    tw = time.time()
-    O.train_steps(cfg, params, feats, labels, sample_batch, 1)  # warm-up
-    log(f"cpu baseline warm-up step: {time.time() - tw:.1f} s on {cores} threads")
-    # bounded sample: as many timed steps as fit ~budget_s of CPU work (the warm-up step sizes them)
-    steps = max(1, min(max_steps, int(budget_s / max(time.time() - tw, 1e-3))))
-    t0 = time.time()
-    O.train_steps(cfg, params, feats[sample_batch:], labels[sample_batch:], sample_batch, steps)
-    dt = time.time() - t0
-    return {"value": CLIP_SECONDS * sample_batch * steps / dt, "unit": "audio-seconds/sec", "cores": cores,
-            "kind": "port",
-            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, "
-                      f"batch {sample_batch}, {steps} timed steps after 1 warm-up, {dt / steps:.2f} s/step"}
+GF_PER_SAMPLE_BY_SIZE = {"tiny": 141.3, "small": 449.1, "large": 8320.6}  # SURVEY.md 8(d), 30 s clips
+W2V_GF_PER_SAMPLE = {"base": 83.43}                                        # SURVEY.md 8(d), 2 s clips
+POD_CPU_LIMIT = 5                # sample_tfjobs/whisper-dist.yaml:36
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def bench_wav2vec2(args, strategy, dev, rank, world):
-    """Secondary workload (BASELINE configs[3]): Wav2Vec2-base pre-training step, 2 s clips."""
+# ------------------------------------------------------------------------------------ CPU baseline
+def host_cpu():
+    """(model string, threads for 'all physical cores of one socket this process may use', nproc)."""
+    model, per_socket = "unknown", None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("cpu cores") and per_socket is None:
+                per_socket = int(line.split(":", 1)[1])
+    except Exception:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    share = int(os.environ.get("TMI_BENCH_CPU_SHARE", "16"))  # a 1-GPU box's CPU share: more threads only thrash
+    threads = max(1, min(avail, per_socket or avail, share))
+    return model, threads, avail
+
+
+def _time_oracle(run_steps, threads, warm, timed):
+    """run_steps(n) advances the oracle n steps and returns their losses."""
+    import torch
+    torch.set_num_threads(threads)
+    losses = []
+    if warm:
+        t0 = time.time()
+        losses += run_steps(warm)
+        log(f"cpu baseline ({threads} threads) warm-up: {(time.time() - t0) / warm:.1f} s/step")
+    t0 = time.time()
+    losses += run_steps(timed)
+    return (time.time() - t0) / timed, losses
+
+
+def cpu_baseline_whisper(model_type, batch, dev, budget_s):
+    """Oracle fp32 on the bench batch (pool seed 1234, batch ``batch``, 30 s clips).  Setting 1: 1 warm-up + as many
+    timed steps as fit ~budget_s (at most 3); setting 2 (5 threads): continues from there for 1 step (no new warm-up:
+    the CPU path compiles nothing).  The GPU fp32 path then runs the same steps from the same initial weights."""
     import numpy as np
     import torch
-    from tethys_speech_amd import ops, optim, train, wav2vec2
-    from tethys_speech_amd.data import W2VDummyDataset
-    size = "base" if args.model_type == "small" else args.model_type
-    model = wav2vec2.create_full_model("pretraining", size, device=dev, precision=args.precision, seed=1234)
-    strategy.broadcast_parameters(model.arena.p)
-    model.refresh_shadows()
-    if args.dropout == "reference":
-        c = model.config
-        model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=1234 * 1000003 + rank, act_p=c.activation_dropout)
-    opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
-    ds = W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234)
-    it = iter(ds)
-    rng = np.random.default_rng(1235)
-    negs = [torch.from_numpy(wav2vec2.sample_negative_indices(rng, args.batch_size, 100, 100)).to(dev)
-            for _ in range(args.steps + args.warmup)]
+    from oracle import whisper_oracle as O  # checker, timed as the CPU baseline only
+    cpu_model, threads, nproc = host_cpu()
+    cfg = O.make_config(model_type, dropout=0.0, attention_dropout=0.0, activation_dropout=0.0)
+    params = O.init_params(cfg, seed=1234, dtype=torch.float32)
+    params0 = {k: v.clone() for k, v in params.items()}
+    feats, labels = O.create_dummy_pool(seed=1234)
+    it = O.batches(feats, labels, batch)
+    state = O.AdamState()
+    used = []
 
-    def one_step(i):
-        return train.wav2vec2_train_step(strategy, model, next(it), negs[i], opt)
+    def run_steps(n):
+        out = []
+        for _ in range(n):
+            f, l = next(it)
+            used.append((f, l))
+            loss, g = O.loss_and_grads(params, torch.from_numpy(np.ascontiguousarray(f)), torch.from_numpy(np.ascontiguousarray(l)), cfg)
+            O.adam_step(params, g, state, lr=1e-4)
+            out.append(float(loss))
+        return out
 
-    for i in range(args.warmup):
-        one_step(i)
-    strategy.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = one_step(args.warmup + i)
-    torch.cuda.synchronize()
-    strategy.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    log(f"wav2vec2-{size}: {dt / args.steps * 1e3:.2f} ms/step, loss {float(loss.item()):.4f}")
-    if rank == 0:
-        gb = args.batch_size * world
-        print(json.dumps({
-            "metric": "audio-seconds/sec/node (Wav2Vec2-base pretrain step, 2 s clips)", "value": 2.0 * gb * args.steps / dt,
-            "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]",
-                       "dropout": "reference rates (0.1 / 0.1 / 0.1)" if args.dropout == "reference" else "off",
-                       "global_batch": gb, "parallelism": f"dp{world}", "last_loss": float(loss.item())}}))
-    if world > 1:
-        torch.distributed.destroy_process_group()
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch_size", type=int, default=8, help="per-GPU batch")
-    ap.add_argument("--model_type", default="small")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2"],
-                    help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips)")
-    ap.add_argument("--dropout", choices=["off", "reference"], default="reference",
-                    help="reference (default): the reference's training-mode Dropout layers (W:29-30, rates 0.1 / 0.1) are "
-                         "active, as in its distributed_train_step (training=True), with counter-based masks; "
-                         "off: rates 0, the configuration the loss-curve parity tests pin")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
-    import torch
+    t0 = time.time()
+    first = run_steps(1)
+    warm_s = time.time() - t0
+    log(f"cpu baseline warm-up step: {warm_s:.1f} s on {threads} threads ({cpu_model})")
+    torch.set_num_threads(threads)
+    n1 = max(1, min(3, int(budget_s / max(warm_s, 1e-3))))
+    s1, l1 = _time_oracle(run_steps, threads, 0, n1)
+    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, 1)
+    cpu_losses = first + l1 + l5
+    # the GPU fp32 (parity) path on the same batches from the same initial weights
     import tethys_speech_amd  # noqa: F401
-    from tethys_speech_amd import dist as D
-    from tethys_speech_amd import ops, optim, train, whisper
-    from tethys_speech_amd.data import create_dummy_dataset
+    from tethys_speech_amd import dist as D, optim, train, whisper
+    check = {"cpu_losses": cpu_losses, "tolerance": 1e-3}
+    try:
+        m = whisper.create_whisper_model(model_type, device=dev, precision="fp32", seed=1234)
+        m.arena.load_ref(params0)
+        opt = optim.Adam(learning_rate=1e-4)
+        strat = D.DataParallelStrategy(0, 1)
+        gl = [float(train.distributed_train_step(strat, m, (torch.from_numpy(np.ascontiguousarray(f)).to(dev),
+                                                            torch.from_numpy(np.ascontiguousarray(l)).to(dev)), opt).item())
+              for f, l in used]
+        diff = max(abs(a - b) for a, b in zip(gl, cpu_losses))
+        check.update({"gpu_fp32_losses": gl, "max_abs_diff": diff, "agree": diff <= 1e-3})
+        log(f"loss cross-check CPU oracle fp32 vs GPU fp32 over {len(gl)} steps: max |d| = {diff:.2e}")
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:  # the cross-check must not lose the bench line
+        check.update({"error": f"{type(e).__name__}: {e}"})
+    clip = 30.0
+    return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, batch {batch}, "
+                      f"30 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
+            "cpu_model": cpu_model, "nproc": nproc,
+            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1},
+                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": 1,
+                          "note": "the reference pod's CPU limit (sample_tfjobs/whisper-dist.yaml:36)"}],
+            "loss_check": check}
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    strategy = D.DataParallelStrategy(rank, world, backend="nccl")
-    if args.workload == "wav2vec2":
-        return bench_wav2vec2(args, strategy, dev, rank, world)
 
-    model = whisper.create_whisper_model(args.model_type, device=dev, precision=args.precision, seed=1234)
-    strategy.broadcast_parameters(model.arena.p)
-    model.refresh_shadows()
-    if args.dropout == "reference":
-        model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=1234 * 1000003 + rank)
-    opt = optim.Adam(learning_rate=1e-4)
-    ds = create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True)
-    it = iter(ds)
+def cpu_baseline_w2v(size, batch, dev, budget_s):
+    import numpy as np
+    import torch
+    from oracle import wav2vec2_oracle as V
+    cpu_model, threads, nproc = host_cpu()
+    cfg = V.make_config(size)
+    params = V.init_params(cfg, seed=1234, dtype=torch.float32)
+    params0 = {k: v.clone() for k, v in params.items()}
+    pool = V.create_dummy_pool(seed=1234)
+    T = V.feature_lengths(cfg, pool.shape[1])[-1]
+    rng = np.random.default_rng(1235)
+    it = V.batches(pool, batch)
+    state = V.AdamState()
+    used = []
 
-    def one_step():
-        return train.distributed_train_step(strategy, model, next(it), opt)
+    def run_steps(n):
+        out = []
+        for _ in range(n):
+            a = next(it)
+            neg = V.sample_negative_indices(rng, batch, T, cfg.num_negatives)
+            used.append((a, neg))
+            loss, g, _ = V.loss_and_grads(params, torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(neg), cfg, 1)
+            g, _ = V.clip_by_global_norm(g, 1.0)
+            g = V.clip_by_norm_each(g, 1.0)
+            V.adam_step(params, g, state, lr=3e-5)
+            out.append(float(loss))
+        return out
 
-    log(f"model ready ({model.arena.n_params} params), warming up {args.warmup} steps")
+    torch.set_num_threads(threads)
+    t0 = time.time()
+    first = run_steps(1)
+    warm_s = time.time() - t0
+    n1 = max(1, min(4, int(budget_s / max(warm_s, 1e-3))))
+    s1, l1 = _time_oracle(run_steps, threads, 0, n1)
+    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, 1)
+    cpu_losses = first + l1 + l5
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train, wav2vec2
+    check = {"cpu_losses": cpu_losses, "tolerance": "2e-3 relative (the loss is O(400): unnormalised logits / 0.1)"}
+    try:
+        m = wav2vec2.create_full_model("pretraining", size, device=dev, precision="fp32", seed=1234)
+        m.arena.load_ref(params0)
+        m.refresh_shadows()
+        opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
+        strat = D.DataParallelStrategy(0, 1)
+        gl = [float(train.wav2vec2_train_step(strat, m, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                              torch.from_numpy(neg).to(dev), opt).item()) for a, neg in used]
+        rel = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(gl, cpu_losses))
+        check.update({"gpu_fp32_losses": gl, "max_rel_diff": rel, "agree": rel <= 2e-3})
+        log(f"loss cross-check CPU oracle fp32 vs GPU fp32 over {len(gl)} steps: max rel = {rel:.2e}")
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:
+        check.update({"error": f"{type(e).__name__}: {e}"})
+    clip = 2.0
+    return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
+            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, wav2vec2-{size} pre-training step (V:), "
+                      f"batch {batch}, 2 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
+            "cpu_model": cpu_model, "nproc": nproc,
+            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1},
+                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": 1,
+                          "note": "the reference pod's CPU limit (sample_tfjobs/wav2vec2-dist.yaml)"}],
+            "loss_check": check}
+
+
+# ------------------------------------------------------------------------------------ roofline probe
+def measure_roofline(model, one_step, nprof, precision, tag):
+    """Instrumented pass: HIP events around every wrapped launch, on the launch stream.  The weight-gradient side
+    stream is switched off for it, so each kernel runs alone and its duration is its own (in the timed region
+    weight gradients overlap the dgrad chain)."""
+    from tethys_speech_amd import ops
+    overlap = model._side is not None
+    model.enable_wgrad_stream(False)
+    ops.PROFILE = ops.OpProfile()
+    for _ in range(nprof):
+        one_step()
+        ops.PROFILE.flush()  # one step per read-out: many outstanding timing events stall the stream
+    prof, ops.PROFILE = ops.PROFILE, None
+    model.enable_wgrad_stream(overlap)
+    mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+    classes = []
+    for cls, bound, peak, unit, scale in (("gemm", "mfma", mfma_peak, "TFLOP/s", 1e12),
+                                          ("attention", "mfma", mfma_peak, "TFLOP/s", 1e12),
+                                          ("adam", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                          ("layernorm", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                          ("groupnorm", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                          ("colsum", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                          ("dropout", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
+                                          ("xent", "hbm", HBM_PEAK_GBS, "GB/s", 1e9)):
+        cm, cw, cn = prof.totals(cls)
+        if cn == 0 or cm <= 0:
+            continue
+        ach = cw / (cm * 1e-3) / scale
+        classes.append({"class": cls, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+                        "ms_per_step": cm / nprof, "launches_per_step": cn / nprof})
+    ms, flops, launches = prof.totals("gemm")
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    # Memory traffic cannot be counted from inside the process: it comes from the last committed PMC passes over this
+    # same command (tools/pmc_traffic.py), bytes per tmi_gemm launch.  FETCH_SIZE / WRITE_SIZE are the L2's fabric-side
+    # counters (Infinity-Cache hits included, guide section HBM), FETCH_SIZE doubled per the gfx950 note.
+    traffic, traffic_src = None, None
+    for name in (f"r02_{tag}_gemm_pmc_traffic.json", f"r01_{tag}_gemm_pmc_traffic.json" if tag != "whisper" else "r01_gemm_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+            traffic = pmc.get("fabric_bytes_per_launch", pmc.get("hbm_bytes_per_launch"))
+            traffic_src = f"profiles/{name}: " + pmc["source"]
+            break
+        except Exception:
+            continue
+    roof = {"bound": "mfma", "kernel": "tmi_gemm kernels (every Dense / Conv1D forward, dgrad and wgrad GEMM of the step)",
+            "achieved": achieved, "peak": mfma_peak, "unit": "TFLOP/s", "frac": achieved / mfma_peak,
+            "traffic": traffic,
+            "traffic_unit": "L2 fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, so an upper bound on HBM bytes)",
+            "traffic_source": traffic_src, "launches_per_step": launches / nprof, "gemm_ms_per_step": ms / nprof,
+            "gemm_gflop_per_step": flops / nprof / 1e9, "avg_launch_us": ms * 1e3 / max(1, launches)}
+    return roof, classes
+
+
+def timed_region(one_step, args, strategy, dev, world):
+    import torch
     for i in range(args.warmup):
         tw = time.perf_counter()
         one_step()
         torch.cuda.synchronize()
-        log(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
+        if i < 3:
+            log(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     strategy.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -191,76 +291,114 @@ def main():
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
-    last_loss = float(loss.item())
+    return float(tmax.item()), float(loss.item()), t_host / args.steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=250, help="timed steps (default: > 2 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch_size", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--model_type", default="small")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2"],
+                    help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips)")
+    ap.add_argument("--dropout", choices=["off", "reference"], default=None,
+                    help="reference (default on bf16): the reference's training-mode Dropout layers (W:29-30, rates 0.1 / 0.1) are "
+                         "active, as in its distributed_train_step (training=True), with counter-based masks; "
+                         "off: rates 0, the configuration the loss-curve parity tests pin (and the fp32 path's only mode)")
+    ap.add_argument("--grad_dtype", choices=["fp32", "bf16"], default="fp32", help="wire dtype of the gradient exchange (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of timed CPU work for the first thread setting")
+    args = ap.parse_args()
+    if args.dropout is None:
+        args.dropout = "reference" if args.precision == "bf16" else "off"
+
+    import numpy as np
+    import torch
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    from tethys_speech_amd import optim, train
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    strategy = D.DataParallelStrategy(rank, world, backend=os.environ.get("TETHYS_DIST_BACKEND", "nccl"),
+                                      grad_dtype=args.grad_dtype)
+    drop_note = ("reference rates, counter-based masks" if args.dropout == "reference"
+                 else "off (rates 0: the configuration the parity tests pin)")
+    dtype_name = "bf16" if args.precision == "bf16" else "f32"
+
+    if args.workload == "whisper":
+        from tethys_speech_amd import whisper
+        from tethys_speech_amd.data import create_dummy_dataset
+        clip = 30.0
+        model = whisper.create_whisper_model(args.model_type, device=dev, precision=args.precision, seed=1234)
+        strategy.broadcast_parameters(model.arena.p)
+        model.refresh_shadows()
+        if args.dropout == "reference":
+            model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=1234 * 1000003 + rank)
+        opt = optim.Adam(learning_rate=1e-4)
+        it = iter(create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True))
+
+        def one_step():
+            return train.distributed_train_step(strategy, model, next(it), opt)
+        c = model.config
+        metric = f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)"
+        workload = (f"whisper-{args.model_type}-ref (reference '{args.model_type}': {c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, "
+                    f"{c.encoder_layers}+{c.decoder_layers} layers) train step, per-GPU batch {args.batch_size}, 30 s clips [80x3000], S=100")
+        gf_sample = GF_PER_SAMPLE_BY_SIZE.get(args.model_type)
+        tag = "whisper" if args.model_type == "small" else f"whisper_{args.model_type}"
+    else:
+        from tethys_speech_amd import wav2vec2
+        from tethys_speech_amd.data import W2VDummyDataset
+        clip = 2.0
+        size = "base" if args.model_type == "small" else args.model_type
+        model = wav2vec2.create_full_model("pretraining", size, device=dev, precision=args.precision, seed=1234)
+        strategy.broadcast_parameters(model.arena.p)
+        model.refresh_shadows()
+        if args.dropout == "reference":
+            c = model.config
+            model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=1234 * 1000003 + rank, act_p=c.activation_dropout)
+        opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
+        it = iter(W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234))
+        rng = np.random.default_rng(1235)
+        # the reference draws its negative indices on the device inside the step; here they are a step input, drawn with
+        # its recipe: a ring of pre-drawn index sets already resident in HBM (like the audio batches)
+        negs = [torch.from_numpy(wav2vec2.sample_negative_indices(rng, args.batch_size, 100, 100)).to(dev) for _ in range(64)]
+        ctr = [0]
+
+        def one_step():
+            ctr[0] += 1
+            return train.wav2vec2_train_step(strategy, model, next(it), negs[ctr[0] % len(negs)], opt)
+        metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
+        workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
+        gf_sample = W2V_GF_PER_SAMPLE.get(size)
+        tag = f"wav2vec2_{size}"
+
+    log(f"model ready ({model.arena.n_params} params), warming up {args.warmup} steps")
+    dt, last_loss, host_ms = timed_region(one_step, args, strategy, dev, world)
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step, loss {last_loss:.4f}")
 
-    roof = None
+    roof = classes = None
     if not args.no_roofline:
-        # instrumented pass: HIP events around every tmi_gemm launch, on the launch stream.  The
-        # weight-gradient side stream is switched off for it, so each GEMM runs alone and its
-        # duration is its own (in the timed region above weight gradients overlap the dgrad chain).
-        overlap = model._side is not None
-        model.enable_wgrad_stream(False)
-        # One step per probe object, read out before the next: with more than ~500 timing events
-        # outstanding the runtime stalls the stream for ~50 ms on a record, which is not GEMM time.
-        nprof = min(args.steps, 3)
-        ops.PROFILE = ops.OpProfile()
-        for _ in range(nprof):
-            one_step()
-            ops.PROFILE.flush()
-        prof, ops.PROFILE = ops.PROFILE, None
-        ms, flops, launches = prof.totals("gemm")
-        model.enable_wgrad_stream(overlap)
-        # the other kernel classes, each against the roof that bounds it ("report per kernel class")
-        classes = []
-        for cls, bound, peak, unit, scale in (("gemm", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12),
-                                              ("attention", "mfma", MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12),
-                                              ("adam", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
-                                              ("layernorm", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
-                                              ("colsum", "hbm", HBM_PEAK_GBS, "GB/s", 1e9),
-                                              ("xent", "hbm", HBM_PEAK_GBS, "GB/s", 1e9)):
-            cm, cw, cn = prof.totals(cls)
-            if cn == 0 or cm <= 0:
-                continue
-            ach = cw / (cm * 1e-3) / scale
-            classes.append({"class": cls, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
-                            "ms_per_step": cm / nprof, "launches_per_step": cn / nprof})
-        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM traffic cannot be counted from inside the process: it comes from the last committed PMC
-        # passes over this same command (tools/pmc_traffic.py), bytes per tmi_gemm launch
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_gemm_pmc_traffic.json: " + pmc["source"]
-        except Exception:
-            pass
-        roof = {"bound": "mfma", "kernel": "tmi_gemm kernels (gemm_fast_kernel / gemm_p8_kernel / gemm_kernel: all Dense/Conv1D fwd, dgrad, wgrad GEMMs)",
-                "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                "traffic_source": traffic_src,
-                "launches_per_step": launches / nprof, "gemm_ms_per_step": ms / nprof,
-                "gemm_gflop_per_step": flops / nprof / 1e9,
-                "avg_launch_us": ms * 1e3 / max(1, launches)}
+        roof, classes = measure_roofline(model, one_step, min(args.steps, 3), args.precision, tag)
 
     if rank == 0:
         gb = args.batch_size * world
-        value = CLIP_SECONDS * gb * args.steps / dt
-        c = model.config
-        shape_note = f"{c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, {c.encoder_layers}+{c.decoder_layers} layers"
-        gf_sample = GF_PER_SAMPLE_BY_SIZE.get(args.model_type)
         out = {
-            "metric": f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)",
-            "value": value, "unit": "audio-seconds/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"whisper-{args.model_type}-ref (reference '{args.model_type}': {shape_note}) "
-                                   f"train step, per-GPU batch {args.batch_size}, 30 s clips [80x3000], S=100",
-                       "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
-                       "dropout": ("reference rates (0.1 / 0.1), counter-based masks" if args.dropout == "reference"
-                                   else "off (rates 0: the configuration the parity tests pin)"),
+            "metric": metric, "value": clip * gb * args.steps / dt, "unit": "audio-seconds/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": workload, "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
+                       "dropout": drop_note, "grad_exchange_dtype": args.grad_dtype if world > 1 else None,
+                       "host_enqueue_ms_per_step": host_ms,
                        "step_tflops": gf_sample * gb * args.steps / dt / 1e3 if gf_sample else None},
         }
         if roof is not None:
@@ -268,7 +406,12 @@ def main():
             out["roofline_classes"] = classes
         if world == 1 and not args.no_cpu_baseline:
             log("timing the restated reference CPU path (oracle) on the host cores")
-            out["cpu_baseline"] = cpu_baseline(args.model_type, 3000)
+            del model
+            torch.cuda.empty_cache()
+            if args.workload == "whisper":
+                out["cpu_baseline"] = cpu_baseline_whisper(args.model_type, args.batch_size, dev, args.cpu_budget)
+            else:
+                out["cpu_baseline"] = cpu_baseline_w2v(size, args.batch_size, dev, args.cpu_budget)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

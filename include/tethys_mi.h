@@ -220,6 +220,16 @@ int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, f
                       float gscale, void* bf16_mirror, void* stream);
 
 
+/* Gradient exchange staging (C1, W:834 / V:1246: the implicit cross-replica SUM of every gradient; the
+ * exchange itself is RCCL through torch.distributed, these are the device-side passes around it).
+ * tmi_grad_pack:   dst[i] = bf16(src[i] * scale) - an fp32 arena slice onto a bf16 wire buffer.
+ * tmi_grad_unpack: dst[i] = scale * sum_{p < nparts} src[p*part_stride + i], src bf16 or fp32, fp32 sum:
+ *   the widening of a reduced bf16 bucket (nparts = 1) and the local reduction of the nparts pieces a mesh
+ *   reduce-scatter (all-to-all over the xGMI links) delivers. */
+int tmi_grad_pack(const float* src, void* dst, int64_t n, float scale, void* stream);
+int tmi_grad_unpack(const void* src, int32_t src_dtype, int64_t nparts, int64_t part_stride, float* dst,
+                    int64_t n, float scale, void* stream);
+
 /* bf16 shadows of fp32 master weights: dst[r*ldd + c] = bf16(src[r*lds + c]) and the
  * transposed form dst[c*ldd + r] = bf16(src[r*lds + c]); pad columns [cols, ldd) of the
  * plain form are written as zero. */

@@ -69,3 +69,82 @@ def test_wav2vec2_base_full_size_properties(dev):
     g2 = model.arena.g.clone()
     assert abs(2.0 * l2 - l1) <= 2e-3 * abs(l1)
     assert float((2.0 * g2 - g1).norm() / g1.norm()) <= 2e-2
+
+
+def test_whisper_large_one_layer_each_matches_oracle(dev):
+    """BASELINE configs[4] dimensions (Whisper "large", W:880-886: d_model 1280, 20 heads, d_ff 5120) with ONE encoder
+    and ONE decoder layer, full-length clips (T = 1500, S = 100), full vocabulary, B = 2: loss and every gradient of
+    the step against the fp64 oracle.  d = 1280 / H = 20 take other tile-selection branches than small-ref
+    (profiles/r01_gemm_rule_probe.txt).  fp32 path: loss 1e-4, gradients 2e-4 of max|ref| per tensor; bf16 path:
+    loss 2e-2, gradients 6e-2 relative L2."""
+    import numpy as np
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import whisper
+    from oracle import whisper_oracle as O
+    torch.set_num_threads(16)
+    ocfg = O.make_config("large", encoder_layers=1, decoder_layers=1, dropout=0.0, attention_dropout=0.0)
+    assert (ocfg.d_model, ocfg.encoder_attention_heads, ocfg.d_ff) == (1280, 20, 5120)
+    params = O.init_params(ocfg, seed=7, dtype=torch.float64)
+    g = torch.Generator().manual_seed(7)
+    for k, v in params.items():  # biases / LN offsets away from their zero init, so their paths are exercised
+        if k.endswith(".bias") or k.endswith(".beta"):
+            v.copy_(torch.randn(v.shape, generator=g, dtype=torch.float64) * 0.02)
+    feats, labels = O.create_dummy_pool(seed=7, num_samples=2)
+    loss_ref, grads_ref = O.loss_and_grads(params, torch.from_numpy(feats), torch.from_numpy(labels), ocfg)
+    for precision, ltol in (("fp32", 1e-4), ("bf16", 2e-2)):
+        model = whisper.create_whisper_model("large", device=dev, precision=precision, encoder_layers=1, decoder_layers=1)
+        model.arena.load_ref(params)
+        model.refresh_shadows()
+        loss = float(model.forward_backward(torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev)).item())
+        assert abs(loss - float(loss_ref)) <= ltol, (precision, loss, float(loss_ref))
+        got = model.arena.ref_views(model.arena.g)
+        bad = {}
+        for k, gr in grads_ref.items():
+            gg = got[k].double().cpu()
+            if k.endswith("k_proj.bias"):
+                # softmax is shift-invariant per row: the true gradient is exactly zero (the oracle's is fp64 noise);
+                # hold the computed one to a fraction of the sibling q_proj.bias gradient's magnitude
+                ref_scale = float(grads_ref[k.replace("k_proj", "q_proj")].abs().max())
+                lim = (1e-4 if precision == "fp32" else 2e-2) * ref_scale
+                if float(gg.abs().max()) > lim:
+                    bad[k] = float(gg.abs().max()) / ref_scale
+                continue
+            if precision == "fp32":
+                err = float((gg - gr).abs().max() / max(float(gr.abs().max()), 1e-12))
+                if err > 2e-4:
+                    bad[k] = err
+            else:
+                err = float((gg - gr).norm() / max(float(gr.norm()), 1e-3))
+                if err > 6e-2:
+                    bad[k] = err
+        assert not bad, (precision, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+        del model
+        torch.cuda.empty_cache()
+
+
+def test_whisper_large_full_size_properties(dev):
+    """BASELINE configs[4]: ``create_whisper_model("large")`` (1280 / 20 heads / 5120 / 32+32, 1,607,321,600
+    parameters), per-GPU batch 8, bf16, dropout off: the size-independent properties of the small-ref test."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import whisper
+    from tethys_speech_amd.data import create_dummy_dataset
+    model = whisper.create_whisper_model("large", device=dev, precision="bf16", seed=1234)
+    assert model.arena.n_params == 1_607_321_600
+    feats, labels = next(iter(create_dummy_dataset(8, device=dev, seed=1234, drop_remainder=True)))
+    loss8 = float(model.forward_backward(feats, labels).item())
+    g8 = model.arena.g.clone()
+    views = model.arena.ref_views(g8)
+    assert abs(loss8 - math.log(51865)) < 0.15, loss8
+    assert all(bool(torch.isfinite(v).all()) for v in views.values())
+    scale = max(float(v.abs().max()) for k, v in views.items() if k.endswith("q_proj.bias"))
+    worst_k = max(float(v.abs().max()) for k, v in views.items() if k.endswith("k_proj.bias"))
+    assert worst_k <= 2e-2 * scale, (worst_k, scale)
+    assert float(model.arena.view(g8, "lm_head.kernel")[:, 51865:].abs().max()) == 0.0
+    la = float(model.forward_backward(feats[:4].contiguous(), labels[:4].contiguous()).item())
+    ga = model.arena.g.clone()
+    lb = float(model.forward_backward(feats[4:].contiguous(), labels[4:].contiguous()).item())
+    ga += model.arena.g
+    assert abs(0.5 * (la + lb) - loss8) <= 1e-4 * abs(loss8)
+    rel = float((0.5 * ga - g8).norm() / g8.norm())
+    print(f"whisper-large DP identity: rel {rel:.2e}, loss8 {loss8:.4f}")
+    assert rel <= 2e-2, rel

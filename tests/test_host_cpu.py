@@ -147,9 +147,9 @@ def _dp_worker(rank, world, port, q):
     n = gflat.numel()
     strat.gradients_ready(2 * n // 3, n)
     strat.gradients_ready(n // 3, 2 * n // 3)
-    launched = len(strat._works)
+    launched = n - strat._pend_hi  # elements already handed to the exchange while "backward" was still running
     strat.all_reduce_gradients(gflat)  # sends the remaining head and waits for every bucket
-    assert launched >= 1
+    assert launched > 0
     g2 = torch.cat([g[k].reshape(-1) for k in names])
     strat.all_reduce_gradients(g2)     # plain bucketed form gives the same sums
     assert torch.equal(g2, gflat)
@@ -261,3 +261,56 @@ def test_empty_slice_replica_issues_the_same_collectives():
     assert l0 == l1 and len(l0) >= 3          # same buckets, same order, more than one of them
     assert l0[0][1] > l0[-1][1] and l0[-1][0] == 0
     assert np.array_equal(g0, g1) and np.array_equal(g0, want)  # zeros + rank 0's gradients
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D
+    torch.set_num_threads(2)
+    base = D.DataParallelStrategy(rank, world, backend="gloo", bucket_bytes=4 * 1000)
+    gen = torch.Generator().manual_seed(100 + rank)
+    n = 10_007  # not a multiple of the bucket size, the world size or the 8-element piece alignment
+    g0 = torch.randn(n, generator=gen)
+    out = {}
+    for exchange in ("allreduce", "rs_ag", "mesh"):
+        for gd in ("fp32", "bf16"):
+            s = D.DataParallelStrategy(rank, world, bucket_bytes=4 * 1000, init=False, grad_dtype=gd, exchange=exchange)
+            g = g0.clone()
+            # overlapped form: three reports, then the rest
+            s.begin_gradients(g)
+            s.gradients_ready(7000, n)
+            s.gradients_ready(3001, 7000)
+            s.all_reduce_gradients(g)
+            g2 = g0.clone()
+            s.all_reduce_gradients(g2)  # plain bucketed form
+            out[(exchange, gd)] = (g.numpy().copy(), g2.numpy().copy())
+    q.put((rank, g0.numpy(), out))
+    dist.destroy_process_group()
+
+
+def test_exchange_forms_and_bf16_wire_two_rank_gloo():
+    """reduce-scatter + all-gather and the all-links mesh form give the all-reduce's sums; bf16 on
+    the wire stays within bf16 rounding of the fp32 exchange (2 addends: <= 2^-8 relative per element of the larger
+    addend's magnitude)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, a, out0), (_, b, out1) = res
+    want = a + b
+    for key in out0:
+        for got in (*out0[key], *out1[key]):
+            if key[1] == "fp32":
+                assert np.allclose(got, want, rtol=0, atol=1e-6), key
+            else:
+                bound = (np.abs(a) + np.abs(b)) * 2.0 ** -7 + 1e-6
+                assert np.all(np.abs(got - want) <= bound), (key, float(np.abs(got - want).max()))
+        assert np.array_equal(out0[key][0], out1[key][0]), key  # replicas end with identical gradients

@@ -88,6 +88,8 @@ SIGNATURES = {
     "tmi_posconv_pack_weights": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_grad_pack": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    "tmi_grad_unpack": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp]),
     "tmi_contrastive_fwd_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp]),
     "tmi_segment_sumsq": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tmi_segment_clip": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),

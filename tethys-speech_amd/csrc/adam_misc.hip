@@ -284,6 +284,95 @@ extern "C" int tmi_cast_bf16(const float* src, int64_t lds_, void* dst, int64_t 
   return tmi_check_launch("tmi_cast_bf16");
 }
 
+// ---- gradient exchange staging (dist.py): fp32 arena slice <-> wire buffer
+// pack: dst = bf16(src * scale); unpack: dst[i] = scale * sum_p src[p * part_stride + i] (src bf16 or fp32): the
+// widening of a reduced bf16 bucket (nparts = 1) and the local sum of the N pieces a mesh reduce-scatter delivers.
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n,
+                                                        float scale, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + 8 * i), b = *reinterpret_cast<const f32x4*>(src + 8 * i + 4);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = (bf16_t)(a[j] * scale); o[4 + j] = (bf16_t)(b[j] * scale); }
+      *reinterpret_cast<bf16x8*>(dst + 8 * i) = o;
+    }
+    for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)(src[i] * scale);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = (bf16_t)(src[i] * scale);
+  }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const TS* __restrict__ src, int64_t nparts, int64_t part_stride,
+                                                          float* __restrict__ dst, int64_t n, float scale, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int64_t p = 0; p < nparts; ++p) {
+        const TS* s = src + p * part_stride + 8 * i;
+        if constexpr (sizeof(TS) == 2) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(s);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        } else {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        }
+      }
+      *reinterpret_cast<f32x4*>(dst + 8 * i) = f32x4{acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale};
+      *reinterpret_cast<f32x4*>(dst + 8 * i + 4) = f32x4{acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale};
+    }
+    for (int64_t i = (nv << 3) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      float a = 0.f;
+      for (int64_t p = 0; p < nparts; ++p) a += (float)src[p * part_stride + i];
+      dst[i] = a * scale;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+      float a = 0.f;
+      for (int64_t p = 0; p < nparts; ++p) a += (float)src[p * part_stride + i];
+      dst[i] = a * scale;
+    }
+  }
+}
+
+extern "C" int tmi_grad_pack(const float* src, void* dst, int64_t n, float scale, void* stream) {
+  if (!src || !dst || n <= 0) {
+    tmi_set_error("tmi_grad_pack: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  const int vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) ? 1 : 0;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(grad_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src,
+                     (bf16_t*)dst, n, scale, vec);
+  return tmi_check_launch("tmi_grad_pack");
+}
+
+extern "C" int tmi_grad_unpack(const void* src, int32_t src_dtype, int64_t nparts, int64_t part_stride, float* dst,
+                               int64_t n, float scale, void* stream) {
+  if (!src || !dst || n <= 0 || nparts <= 0 || (nparts > 1 && part_stride < n) || (src_dtype != TMI_F32 && src_dtype != TMI_BF16)) {
+    tmi_set_error("tmi_grad_unpack: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  const int vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 &&
+                   (nparts == 1 || part_stride % 8 == 0)) ? 1 : 0;
+  int64_t blocks = (n / 8 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (src_dtype == TMI_BF16)
+    hipLaunchKernelGGL(grad_unpack_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)src, nparts, part_stride, dst, n, scale, vec);
+  else
+    hipLaunchKernelGGL(grad_unpack_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, nparts, part_stride, dst, n, scale, vec);
+  return tmi_check_launch("tmi_grad_unpack");
+}
+
 extern "C" int tmi_transpose_cast_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
                                        int64_t cols, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < rows || (cols + 63) / 64 > 65535 * 32) {

@@ -62,23 +62,46 @@ def rendezvous_from_env(env=None) -> Tuple[Optional[str], Optional[str]]:
 
 
 class DataParallelStrategy:
+    """``exchange``: how a bucket is summed over the replicas -
+        "allreduce"  one ``all_reduce`` per bucket (RCCL picks its rings / trees);
+        "rs_ag"      ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` over the same bucket (the two halves of
+                     a ring all-reduce as separate collectives: the form an optimizer working on 1/N shards needs);
+        "mesh"       xGMI is a full point-to-point mesh (7 links per GPU), which a single ring leaves mostly idle:
+                     ``all_to_all_single`` sends piece j of the bucket straight to rank j over the direct link (all
+                     links at once), a local kernel sums the N received pieces (tmi_grad_unpack), and an all-gather
+                     returns the reduced pieces.
+    ``grad_dtype``: "fp32" moves the arena slices as they are (the reference's arithmetic); "bf16" packs each
+    bucket to bf16 when it is launched (half the bytes on the links) and widens the reduced bucket back to fp32
+    before the optimizer reads it; sums across ranks are then bf16 sums (RCCL) - or, with "mesh", fp32 sums of
+    bf16 pieces."""
+
     def __init__(self, rank: int = 0, world: int = 1, backend: Optional[str] = None,
-                 bucket_bytes: int = 24 << 20, init: bool = True):
+                 bucket_bytes: int = 24 << 20, init: bool = True, grad_dtype: Optional[str] = None,
+                 exchange: Optional[str] = None):
         self.rank, self.world = rank, world
         # launch threshold of the overlapped exchange.  24 MiB: every Whisper small-ref layer (28-38 MB of
         # fp32 gradients) goes out as soon as it is final, so what remains exposed after backward is
         # the conv stem's 8 MB, not "last layer + stem" (the big tensors, lm_head / embeddings at 160 MB,
         # are single collectives either way; xGMI rings are per-link bound, large messages are fine)
         self.bucket_bytes = bucket_bytes
+        self.grad_dtype = grad_dtype or os.environ.get("TMI_GRAD_DTYPE", "fp32")
+        self.exchange = exchange or os.environ.get("TMI_EXCHANGE", "allreduce")
+        if self.grad_dtype not in ("fp32", "bf16") or self.exchange not in ("allreduce", "rs_ag", "mesh"):
+            raise ValueError("grad_dtype must be fp32 | bf16 and exchange allreduce | rs_ag | mesh")
         self._g = None
         self._works: List = []
+        self._post: List = []          # per launched bucket: callable run after its works completed (widen / copy back)
+        self._stage = {}               # (lo, hi, kind) -> staging tensor, allocated once
         self._pend_lo = self._pend_hi = 0
+        self._serial = False           # gloo runs queued works on a thread pool: dependent collectives must be waited for
         if world > 1 and init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             addr, port = rendezvous_from_env()
             os.environ["MASTER_ADDR"] = addr or "127.0.0.1"
             os.environ["MASTER_PORT"] = port or "29531"
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if world > 1 and dist.is_initialized():
+            self._serial = dist.get_backend() != "nccl"
 
     @property
     def num_replicas_in_sync(self) -> int:
@@ -103,7 +126,8 @@ class DataParallelStrategy:
         that writes it has been enqueued); ranges arrive contiguous and descending, because the
         arena is in forward order and backward fills it from the end."""
         self._g = g
-        self._works: List = []
+        self._works = []
+        self._post = []
         self._pend_lo = self._pend_hi = g.numel()
 
     def gradients_ready(self, lo: int, hi: int):
@@ -117,13 +141,108 @@ class DataParallelStrategy:
 
     pre_launch = None  # optional hook: order the compute stream after side-stream gradient producers
 
+    def _buf(self, key, n, dtype, like):
+        t = self._stage.get(key)
+        if t is None or t.numel() != n or t.dtype != dtype or t.device != like.device:
+            t = self._stage[key] = torch.empty(n, dtype=dtype, device=like.device)
+        return t
+
+    def _pack(self, src, dst):
+        if src.is_cuda:
+            from . import ops
+            ops.grad_pack(src, dst, src.numel())
+        else:  # (the gloo tests run the strategy on host tensors)
+            dst.copy_(src)
+
+    def _unpack(self, src, dst, nparts=1, part_stride=0):
+        n = dst.numel()
+        if dst.is_cuda:
+            from . import ops
+            ops.grad_unpack(src, dst, n, nparts, part_stride)
+        elif nparts == 1:
+            dst.copy_(src[:n])
+        else:
+            dst.copy_(src[:nparts * part_stride].view(nparts, part_stride)[:, :n].float().sum(0))
+
+    def _on_exchange_stream(self, g, fn):
+        """Run ``fn`` with the exchange stream current (device tensors): staging kernels and collectives are issued
+        there, ordered after everything the compute stream has enqueued so far, so backward never waits for them."""
+        if not g.is_cuda:
+            return fn()
+        from . import ops
+        if getattr(self, "_xs", None) is None:
+            self._xs = torch.cuda.Stream(device=g.device)
+        self._xs.wait_stream(torch.cuda.current_stream(g.device))
+        prev = ops.set_stream(self._xs.cuda_stream)
+        try:
+            with torch.cuda.stream(self._xs):
+                return fn()
+        finally:
+            ops.set_stream(prev)
+
+    def _exchange(self, g: torch.Tensor, lo: int, hi: int):
+        return self._on_exchange_stream(g, lambda: self._exchange_body(g, lo, hi))
+
+    def _exchange_body(self, g: torch.Tensor, lo: int, hi: int):
+        """Launch the SUM of g[lo:hi] over the replicas; appends the async works and, if the result does not land in
+        place, the post-step that moves it there."""
+        N, n = self.world, hi - lo
+        sl = g[lo:hi]
+        wire_dt = torch.bfloat16 if self.grad_dtype == "bf16" else torch.float32
+        works = []
+
+        def issue(fn, *a, **kw):
+            w = fn(*a, async_op=True, **kw)
+            if self._serial:
+                w.wait()
+            else:
+                works.append(w)
+
+        if self.exchange == "allreduce":
+            if wire_dt == torch.float32:
+                issue(dist.all_reduce, sl, op=dist.ReduceOp.SUM)
+                post = None
+            else:
+                wire = self._buf((lo, hi, "wire"), n, wire_dt, g)
+                self._pack(sl, wire)
+                issue(dist.all_reduce, wire, op=dist.ReduceOp.SUM)
+                post = lambda: self._unpack(wire, sl)
+        else:
+            per = -(-n // N)
+            per = -(-per // 8) * 8            # 16-byte pieces in either dtype
+            padded = per * N
+            wire = self._buf((lo, hi, "wire"), padded, wire_dt, g)
+            if padded > n:
+                wire[n:].zero_()
+            if wire_dt == torch.float32:
+                wire[:n].copy_(sl)
+            else:
+                self._pack(sl, wire[:n])
+            shard = self._buf((lo, hi, "shard"), per, wire_dt, g)
+            if self.exchange == "rs_ag":
+                issue(dist.reduce_scatter_tensor, shard, wire, op=dist.ReduceOp.SUM)
+                issue(dist.all_gather_into_tensor, wire, shard)
+                post = lambda: self._unpack(wire, sl)
+            else:  # mesh: piece j goes straight to rank j; fp32 sum of the N received pieces here
+                recv = self._buf((lo, hi, "recv"), padded, wire_dt, g)
+                w = dist.all_to_all_single(recv, wire, async_op=True)
+                w.wait()  # (orders the exchange stream after the all-to-all; the host does not block on RCCL)
+                red = self._buf((lo, hi, "red"), per, torch.float32, g)
+                self._unpack(recv, red, nparts=N, part_stride=per)
+                full = self._buf((lo, hi, "full"), padded, torch.float32, g)
+                issue(dist.all_gather_into_tensor, full, red)
+                post = lambda: sl.copy_(full[:n])
+        self._works.extend(works)
+        if post is not None:
+            self._post.append(post)
+
     def _launch(self):
         if self._pend_hi > self._pend_lo:
             if self.pre_launch is not None:
                 self.pre_launch()
             # RCCL orders this after everything already enqueued on the compute stream and runs it
             # on its own stream, under the rest of backward
-            self._works.append(dist.all_reduce(self._g[self._pend_lo:self._pend_hi], op=dist.ReduceOp.SUM, async_op=True))
+            self._exchange(self._g, self._pend_lo, self._pend_hi)
             self._pend_hi = self._pend_lo
 
     def all_reduce_gradients(self, g: torch.Tensor):
@@ -136,13 +255,20 @@ class DataParallelStrategy:
         if getattr(self, "_g", None) is g:
             self._pend_lo = 0
             self._launch()
-            works = self._works
         else:
-            works = [dist.all_reduce(g[s:e], op=dist.ReduceOp.SUM, async_op=True) for s, e in self.buckets(g.numel())]
-        for w in works:
-            w.wait()
+            self._works, self._post = [], []
+            for s_, e in self.buckets(g.numel()):
+                self._exchange(g, s_, e)
+        def finish():
+            for w in self._works:
+                w.wait()
+            for fn in self._post:
+                fn()
+        self._on_exchange_stream(g, finish)
+        if g.is_cuda:  # the optimizer (compute stream) is the first consumer
+            torch.cuda.current_stream(g.device).wait_stream(self._xs)
         self._g = None
-        self._works = []
+        self._works, self._post = [], []
 
     def reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
         """C2: strategy.reduce(SUM, per_replica_losses, axis=None) (W:848)."""

@@ -289,6 +289,15 @@ def adam_step_dev(p, g, m, v, n, beta1, beta2, eps, dev_scalars, eps_mode=0, gsc
                                   dev_scalars.data_ptr(), eps_mode, gscale, ptr(mirror), stream()), "tmi_adam_step_dev")
 
 
+def grad_pack(src, dst, n, scale=1.0):
+    check(lib().tmi_grad_pack(src.data_ptr(), dst.data_ptr(), n, scale, stream()), "tmi_grad_pack")
+
+
+def grad_unpack(src, dst, n, nparts=1, part_stride=0, scale=1.0):
+    check(lib().tmi_grad_unpack(src.data_ptr(), dt(src), nparts, part_stride, dst.data_ptr(), n, scale, stream()),
+          "tmi_grad_unpack")
+
+
 def cast_bf16(src, lds, dst, ldd, rows, cols, src_off=0, dst_off=0):
     check(lib().tmi_cast_bf16(src.data_ptr() + 4 * src_off, lds, dst.data_ptr() + 2 * dst_off, ldd, rows, cols,
                               stream()), "tmi_cast_bf16")
