@@ -271,20 +271,24 @@ def measure_roofline(model, one_step, nprof, precision, tag):
 
 
 def timed_region(one_step, args, strategy, dev, world):
+    """The contract's timing: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier + device
+    synchronize on both sides; returns the MAX over ranks of the wall time (every rank gets the same number)."""
     import torch
+    on_gpu = str(dev).startswith("cuda")
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     for i in range(args.warmup):
         tw = time.perf_counter()
         one_step()
-        torch.cuda.synchronize()
+        sync()
         if i < 3:
             log(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
     strategy.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = one_step()
     t_host = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside a step)
-    torch.cuda.synchronize()
+    sync()
     strategy.barrier()
     dt = time.perf_counter() - t0
     log(f"host enqueue {t_host / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step wall")
@@ -292,6 +296,11 @@ def timed_region(one_step, args, strategy, dev, world):
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     return float(tmax.item()), float(loss.item()), t_host / args.steps * 1e3
+
+
+def throughput(clip_seconds, per_gpu_batch, world, steps, dt):
+    """Whole-job audio-seconds/sec: weak scaling, the per-GPU batch is fixed as N grows."""
+    return clip_seconds * per_gpu_batch * world * steps / dt
 
 
 def main():
@@ -393,7 +402,7 @@ def main():
     if rank == 0:
         gb = args.batch_size * world
         out = {
-            "metric": metric, "value": clip * gb * args.steps / dt, "unit": "audio-seconds/sec", "n_gpus": world,
+            "metric": metric, "value": throughput(clip, args.batch_size, world, args.steps, dt), "unit": "audio-seconds/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": workload, "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,

@@ -314,3 +314,51 @@ def test_exchange_forms_and_bf16_wire_two_rank_gloo():
                 bound = (np.abs(a) + np.abs(b)) * 2.0 ** -7 + 1e-6
                 assert np.all(np.abs(got - want) <= bound), (key, float(np.abs(got - want).max()))
         assert np.array_equal(out0[key][0], out1[key][0]), key  # replicas end with identical gradients
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+    import types
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import data, dist as D
+    import bench
+    strat = D.DataParallelStrategy(rank, world, backend="gloo")
+    ds = iter(data.create_dummy_dataset(4, n_mels=4, seq_len=16, device="cpu", rank=rank, world=world, seed=1234,
+                                        drop_remainder=True))
+    seen = []
+
+    def one_step():  # a stand-in step: rank 1 is the slow replica
+        f, _ = next(ds)
+        seen.append(f[:, 0, 0].clone())
+        time.sleep(0.02 if rank == 0 else 0.05)
+        return torch.tensor([float(rank)])
+    args = types.SimpleNamespace(steps=5, warmup=2)
+    dt, last, host_ms = bench.timed_region(one_step, args, strat, "cpu", world)
+    q.put((rank, dt, torch.stack(seen).numpy(), bench.throughput(30.0, 4, world, args.steps, dt)))
+    dist.destroy_process_group()
+
+
+def test_bench_timing_logic_two_rank_gloo():
+    """bench.py's N > 1 contract on CPU: the timed region is the MAX over ranks (every rank reports
+    the slow replica's time), replicas read disjoint slices of each global batch, value counts the global batch."""
+    from oracle import whisper_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, dt0, seen0, v0), (_, dt1, seen1, v1) = res
+    assert dt0 == dt1 and v0 == v1
+    assert dt0 >= 5 * 0.05 and dt0 < 5 * 0.05 + 0.5        # the slow rank's 5 timed steps, not the fast rank's
+    assert v0 == pytest.approx(30.0 * 4 * 2 * 5 / dt0)
+    f, _ = O.create_dummy_pool(seed=1234, n_mels=4, seq_len=16)
+    for step in range(7):                                    # 2 warm-up + 5 timed global batches of 8
+        s = (step % 6) * 8
+        assert np.array_equal(seen0[step], f[s:s + 4, 0, 0]) and np.array_equal(seen1[step], f[s + 4:s + 8, 0, 0])

@@ -4,6 +4,7 @@
 // speech_jobs/wav2vec2_dist.py:1271-1275) applied by optimizer.apply_gradients (W:834);
 // tf.transpose + Conv1D "same" padding (W:329, W:311); tf.clip_by_global_norm (V:1243).
 #include "tmi_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -364,7 +365,8 @@ extern "C" int tmi_grad_unpack(const void* src, int32_t src_dtype, int64_t npart
   const int vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 &&
                    (nparts == 1 || part_stride % 8 == 0)) ? 1 : 0;
   int64_t blocks = (n / 8 + 255) / 256;
-  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  static const int64_t cap = [] { const char* e = getenv("TMI_GRAD_BLOCKS"); return e ? atoll(e) : 4096ll; }();
+  blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (src_dtype == TMI_BF16)
     hipLaunchKernelGGL(grad_unpack_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)src, nparts, part_stride, dst, n, scale, vec);

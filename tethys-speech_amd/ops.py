@@ -240,13 +240,20 @@ def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0
         setattr(d, f"{field}_st", st)
     d.delta = delta.data_ptr()
     d.dq_scale = dq_scale
-    with _probe("attention", 10.0 * B * H * Tq * Tk * 64):  # algorithmic: five products (the two passes run seven)
+    # algorithmic work as SURVEY 8(d) defines it: fwd + bwd = 3 x forward, i.e. backward = 2 x 4.B.H.Tq.Tk.64
+    # (the two passes execute seven products: both recompute S and dP)
+    with _probe("attention", 8.0 * B * H * Tq * Tk * 64):
         check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
 
 
 def dropout(x, out, rows, cols, p, seed, resid=None):
     """out = (resid or 0) + Dropout_p(x) over [rows, cols] (row strides from the tensors); the same call on the
     incoming gradient, with the same seed, is the backward.  See tmi_dropout in include/tethys_mi.h."""
+    if PROFILE is not None:
+        with _probe("dropout", (3.0 if resid is not None else 2.0) * rows * cols * x.element_size()):
+            check(lib().tmi_dropout(x.data_ptr(), x.stride(0), ptr(resid), resid.stride(0) if resid is not None else 0,
+                                    out.data_ptr(), out.stride(0), rows, cols, p, seed, dt(x), stream()), "tmi_dropout")
+        return
     check(lib().tmi_dropout(x.data_ptr(), x.stride(0), ptr(resid), resid.stride(0) if resid is not None else 0,
                             out.data_ptr(), out.stride(0), rows, cols, p, seed, dt(x), stream()), "tmi_dropout")
 
@@ -323,6 +330,12 @@ def groupnorm_chunks(T: int) -> int:
 
 
 def groupnorm_gelu_fwd(x, x_sb, gamma, beta, y, y_sb, stats, part, B, T, Cn, G, eps=1e-5, x_off=0, y_off=0):
+    # algorithmic bytes: statistics need the whole (time, C/G) slab before any output, so 2 reads + 1 write
+    with _probe("groupnorm", 3.0 * B * T * Cn * x.element_size()):
+        check(lib().tmi_groupnorm_gelu_fwd(x.data_ptr() + x_off * x.element_size(), x_sb, gamma.data_ptr(), beta.data_ptr(),
+                                           y.data_ptr() + y_off * y.element_size(), y_sb, stats.data_ptr(), part.data_ptr(),
+                                           B, T, Cn, G, eps, dt(x), stream()), "tmi_groupnorm_gelu_fwd")
+    return
     check(lib().tmi_groupnorm_gelu_fwd(x.data_ptr() + x_off * x.element_size(), x_sb, gamma.data_ptr(), beta.data_ptr(),
                                        y.data_ptr() + y_off * y.element_size(), y_sb, stats.data_ptr(), part.data_ptr(),
                                        B, T, Cn, G, eps, dt(x), stream()), "tmi_groupnorm_gelu_fwd")
@@ -331,6 +344,14 @@ def groupnorm_gelu_fwd(x, x_sb, gamma, beta, y, y_sb, stats, part, B, T, Cn, G, 
 def groupnorm_gelu_bwd(x, x_sb, dy, dy_sb, gamma, beta, stats, dx, dx_sb, dgamma, dbeta, part, sums, B, T, Cn, G,
                        x_off=0, dy_off=0, dx_off=0):
     es = x.element_size()
+    # algorithmic bytes: x and dy are each read twice (sums, then dx), dx written once
+    with _probe("groupnorm", 5.0 * B * T * Cn * es):
+        check(lib().tmi_groupnorm_gelu_bwd(x.data_ptr() + x_off * es, x_sb, dy.data_ptr() + dy_off * es, dy_sb,
+                                           gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
+                                           dx.data_ptr() + dx_off * es, dx_sb, dgamma.data_ptr(), dbeta.data_ptr(),
+                                           part.data_ptr(), sums.data_ptr(), B, T, Cn, G, dt(x), stream()),
+              "tmi_groupnorm_gelu_bwd")
+    return
     check(lib().tmi_groupnorm_gelu_bwd(x.data_ptr() + x_off * es, x_sb, dy.data_ptr() + dy_off * es, dy_sb,
                                        gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(),
                                        dx.data_ptr() + dx_off * es, dx_sb, dgamma.data_ptr(), dbeta.data_ptr(),
