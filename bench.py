@@ -221,15 +221,17 @@ def measure_roofline(model, one_step, nprof, precision, tag):
     """Instrumented pass: HIP events around every wrapped launch, on the launch stream.  The weight-gradient side
     stream is switched off for it, so each kernel runs alone and its duration is its own (in the timed region
     weight gradients overlap the dgrad chain)."""
-    from tethys_speech_amd import ops
+    from tethys_speech_amd import ops, train
     overlap = model._side is not None
     model.enable_wgrad_stream(False)
+    adam_overlap, train.ADAM_UNDER_BACKWARD = train.ADAM_UNDER_BACKWARD, False  # the optimizer as one launch, alone
     ops.PROFILE = ops.OpProfile()
     for _ in range(nprof):
         one_step()
         ops.PROFILE.flush()  # one step per read-out: many outstanding timing events stall the stream
     prof, ops.PROFILE = ops.PROFILE, None
     model.enable_wgrad_stream(overlap)
+    train.ADAM_UNDER_BACKWARD = adam_overlap
     mfma_peak = MFMA_BF16_PEAK_TFLOPS if precision == "bf16" else MFMA_F32_PEAK_TFLOPS
     classes = []
     for cls, bound, peak, unit, scale in (("gemm", "mfma", mfma_peak, "TFLOP/s", 1e12),

@@ -204,11 +204,15 @@ int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stre
  *   weight_decay (decoupled, AdamW) defaults to 0 in the reference.
  * bf16_mirror (optional, may be NULL): bf16 copy of the updated parameters, same flat
  * indexing — the k-contiguous / natural-layout weight operand of the bf16 GEMMs.
- * Algorithmic traffic: 28 B/param (read p,g,m,v; write p,m,v) + 2 B/param for the mirror.
+ * zero_grad != 0: g is overwritten with zeros once consumed (the next backward accumulates into it; saves the
+ * separate fill pass).  max_blocks > 0 caps the grid: a slice of the arena updated beside other kernels (the
+ * optimizer running bucket by bucket under backward) must leave them the CUs.
+ * Algorithmic traffic: 28 B/param (read p,g,m,v; write p,m,v) + 2 B/param for the mirror (+ 4 with zero_grad).
  */
-int tmi_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+int tmi_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
-                  float weight_decay, float gscale, void* bf16_mirror, void* stream);
+                  float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
+                  int32_t max_blocks, void* stream);
 /* The step-dependent scalars of tmi_adam_step, computed on the host exactly as it does:
  * out3 = {step_size, vcorr_inv_sqrt, 1 - lr*weight_decay}. */
 int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode,

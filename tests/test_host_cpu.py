@@ -40,7 +40,7 @@ def test_bad_arguments_fail_loudly_without_a_gpu():
     from tethys_speech_amd import _lib
     h = _lib.lib()
     assert h.tmi_gemm(None, None) == -1
-    assert h.tmi_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 1.0, None, None) == -1
+    assert h.tmi_adam_step(None, None, None, None, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0.0, 1.0, None, 0, 0, None) == -1
     with pytest.raises(_lib.TmiError):
         _lib.check(h.tmi_layernorm_fwd(None, None, None, None, None, None, 0, 0, 1e-5, 0, None), "ln")
 

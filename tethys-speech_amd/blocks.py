@@ -210,6 +210,10 @@ class KernelBlocks:
             if ev is not None:
                 (self._main or torch.cuda.current_stream()).wait_event(ev)
 
+    def gradient_streams(self):
+        """Streams other than the compute stream on which gradient-producing kernels are queued."""
+        return [self._side] if self._side is not None else []
+
     def _join_side(self):
         """Main stream waits for everything queued on the weight-gradient stream."""
         if self._side is not None:

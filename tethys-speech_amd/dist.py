@@ -130,8 +130,11 @@ class DataParallelStrategy:
         self._post = []
         self._pend_lo = self._pend_hi = g.numel()
 
+    on_bucket = None   # optional consumer of finished buckets: on_bucket(lo, hi, works, post) takes over waiting for
+                       # the bucket's collectives and running its post-step (optim.Adam updates the slice under backward)
+
     def gradients_ready(self, lo: int, hi: int):
-        if self.world == 1 or self._g is None:
+        if self._g is None or (self.world == 1 and self.on_bucket is None):
             return
         if hi != self._pend_lo:
             raise RuntimeError(f"gradient ranges must be contiguous and descending: got [{lo},{hi}) after {self._pend_lo}")
@@ -139,7 +142,9 @@ class DataParallelStrategy:
         if (self._pend_hi - self._pend_lo) * 4 >= self.bucket_bytes:
             self._launch()
 
-    pre_launch = None  # optional hook: order the compute stream after side-stream gradient producers
+    pre_launch = None  # optional hook run on the compute stream before a bucket is released
+    producers = None   # optional callable -> extra streams that also write gradients (the model's weight-gradient
+                       # stream): the exchange / optimizer streams wait for them directly, the compute stream does not
 
     def _buf(self, key, n, dtype, like):
         t = self._stage.get(key)
@@ -173,6 +178,8 @@ class DataParallelStrategy:
         if getattr(self, "_xs", None) is None:
             self._xs = torch.cuda.Stream(device=g.device)
         self._xs.wait_stream(torch.cuda.current_stream(g.device))
+        for st in (self.producers() if self.producers is not None else ()):
+            self._xs.wait_stream(st)
         prev = ops.set_stream(self._xs.cuda_stream)
         try:
             with torch.cuda.stream(self._xs):
@@ -181,7 +188,16 @@ class DataParallelStrategy:
             ops.set_stream(prev)
 
     def _exchange(self, g: torch.Tensor, lo: int, hi: int):
-        return self._on_exchange_stream(g, lambda: self._exchange_body(g, lo, hi))
+        if self.world == 1:
+            works, post = [], None
+        else:
+            works, post = self._on_exchange_stream(g, lambda: self._exchange_body(g, lo, hi))
+        if self.on_bucket is not None:
+            self.on_bucket(lo, hi, works, post)
+        else:
+            self._works.extend(works)
+            if post is not None:
+                self._post.append(post)
 
     def _exchange_body(self, g: torch.Tensor, lo: int, hi: int):
         """Launch the SUM of g[lo:hi] over the replicas; appends the async works and, if the result does not land in
@@ -232,9 +248,7 @@ class DataParallelStrategy:
                 full = self._buf((lo, hi, "full"), padded, torch.float32, g)
                 issue(dist.all_gather_into_tensor, full, red)
                 post = lambda: sl.copy_(full[:n])
-        self._works.extend(works)
-        if post is not None:
-            self._post.append(post)
+        return works, post
 
     def _launch(self):
         if self._pend_hi > self._pend_lo:
@@ -249,7 +263,7 @@ class DataParallelStrategy:
         """C1: SUM over replicas of the whole gradient arena, bucketed.  If ``begin_gradients``
         opened an overlapped exchange for ``g``, only the not-yet-launched head of the arena is
         sent now; in every case this returns with the compute stream ordered after all buckets."""
-        if self.world == 1:
+        if self.world == 1 and self.on_bucket is None:
             self._g = None
             return
         if getattr(self, "_g", None) is g:
@@ -264,9 +278,10 @@ class DataParallelStrategy:
                 w.wait()
             for fn in self._post:
                 fn()
-        self._on_exchange_stream(g, finish)
-        if g.is_cuda:  # the optimizer (compute stream) is the first consumer
-            torch.cuda.current_stream(g.device).wait_stream(self._xs)
+        if self.world > 1:
+            self._on_exchange_stream(g, finish)
+            if g.is_cuda:  # the optimizer (compute stream) is the first consumer
+                torch.cuda.current_stream(g.device).wait_stream(self._xs)
         self._g = None
         self._works, self._post = [], []
 

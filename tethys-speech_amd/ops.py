@@ -278,10 +278,12 @@ def sum_scale(x, out, n, scale):
     check(lib().tmi_sum_scale(x.data_ptr(), out.data_ptr(), n, scale, stream()), "tmi_sum_scale")
 
 
-def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0, mirror=None):
+def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_decay=0.0, gscale=1.0, mirror=None,
+              zero_grad=False, max_blocks=0):
     with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * n):
         check(lib().tmi_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, lr, beta1, beta2,
-                                  eps, step, eps_mode, weight_decay, gscale, ptr(mirror), stream()), "tmi_adam_step")
+                                  eps, step, eps_mode, weight_decay, gscale, ptr(mirror), 1 if zero_grad else 0,
+                                  max_blocks, stream()), "tmi_adam_step")
 
 
 def adam_scalars(lr, beta1, beta2, step, eps_mode=0, weight_decay=0.0):

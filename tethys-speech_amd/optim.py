@@ -8,6 +8,10 @@ of Keras OptimizerV2), then updates; the same kernel writes the model's bf16 wei
 """
 from __future__ import annotations
 
+import os
+
+import torch
+
 from . import ops
 
 
@@ -22,13 +26,65 @@ class Adam:
         self.weight_decay = float(weight_decay)
         self.iterations = 0
 
-    def apply_gradients(self, model, strategy=None, grad_scale=1.0):
+    def apply_gradients(self, model, strategy=None, grad_scale=1.0, zero_grad=False):
+        """``zero_grad``: the kernel leaves the gradient arena zeroed (``arena.g_clean``), so the next
+        ``forward_backward`` skips its fill pass; callers that still want to look at the gradients pass False."""
         a = model.arena
         if strategy is not None:
             strategy.all_reduce_gradients(a.g)
         self.iterations += 1
         ops.adam_step(a.p, a.g, a.m, a.v, a.numel, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
-                      self.iterations, self.eps_mode, self.weight_decay, grad_scale, mirror=model.mirror)
+                      self.iterations, self.eps_mode, self.weight_decay, grad_scale, mirror=model.mirror,
+                      zero_grad=zero_grad)
+        a.g_clean = bool(zero_grad)
+
+    # -- the update bucket by bucket under backward -------------------------------------------------------------
+    # Adam is a 4.4 GB/step HBM stream (small-ref) that needs nothing but final gradients: instead of one launch
+    # behind backward it runs slice by slice on its own stream as the strategy releases buckets (after the bucket's
+    # all-reduce when there are replicas), on a small grid so that the GEMMs of the remaining backward keep their CUs.
+    # A slice's weights are final in this step once its gradients are: every forward and backward read of them has
+    # been enqueued before the range is reported (KernelBlocks reports whole layers), so updating them - and their
+    # bf16 mirror - under the rest of backward is safe.
+    OVERLAP_BLOCKS = int(os.environ.get("TMI_ADAM_OVERLAP_BLOCKS", "48"))
+
+    def begin_overlapped(self, model, strategy, grad_scale=1.0, zero_grad=True):
+        self.iterations += 1
+        self._ov = (model, grad_scale, zero_grad)
+        if model.device.type == "cuda" and getattr(self, "_os", None) is None:
+            self._os = torch.cuda.Stream(device=model.device)
+        strategy.on_bucket = self._bucket_ready
+        strategy.producers = model.gradient_streams
+        strategy.pre_launch = None
+
+    def _bucket_ready(self, lo, hi, works, post):
+        model, grad_scale, zero_grad = self._ov
+        a = model.arena
+        main = torch.cuda.current_stream(model.device)
+        self._os.wait_stream(main)      # the bucket's producers: the compute stream and the weight-gradient stream
+        for st in model.gradient_streams():
+            self._os.wait_stream(st)
+        prev = ops.set_stream(self._os.cuda_stream)
+        try:
+            with torch.cuda.stream(self._os):
+                for w in works:         # replicas: the optimizer stream (not the host) waits for the bucket's reduce
+                    w.wait()
+                if post is not None:
+                    post()
+                ops.adam_step(a.p[lo:hi], a.g[lo:hi], a.m[lo:hi], a.v[lo:hi], hi - lo, self.learning_rate, self.beta_1,
+                              self.beta_2, self.epsilon, self.iterations, self.eps_mode, self.weight_decay, grad_scale,
+                              mirror=None if model.mirror is None else model.mirror[lo:hi], zero_grad=zero_grad,
+                              max_blocks=self.OVERLAP_BLOCKS)
+        finally:
+            ops.set_stream(prev)
+
+    def finish_overlapped(self, model, strategy):
+        """Release whatever the strategy still holds (the head of the arena), then order the compute stream after the
+        optimizer stream: the step's parameters are final for whoever runs next on it."""
+        strategy.all_reduce_gradients(model.arena.g)
+        strategy.on_bucket = None
+        torch.cuda.current_stream(model.device).wait_stream(self._os)
+        model.arena.g_clean = bool(self._ov[2])
+        self._ov = None
 
     # -- captured-graph form: the launch reads its step-dependent scalars from device memory
     def scalars(self, step=None):

@@ -12,20 +12,36 @@ from .optim import Adam
 from .whisper import create_whisper_model
 
 
+# Adam slice by slice under backward (optim.Adam.begin_overlapped) is OFF by default: measured on MI355X
+# (profiles/r02_adam_under_backward.txt) the step does not get shorter - the concurrent HBM stream slows the GEMMs it
+# runs beside by as much as it saves (p8 weight gradients 130 -> 147 us, fc2 dgrad 101 -> 123 us: 9.55 vs 9.56-9.77
+# ms/step for grids of 16-512 workgroups).  What it does buy everywhere is the zeroing of the gradient arena inside
+# the Adam kernel instead of a separate fill pass.
+ADAM_UNDER_BACKWARD = os.environ.get("TMI_ADAM_UNDER_BACKWARD", "0") != "0"
+
+
 def distributed_train_step(strategy, model, dist_inputs, optimizer):
     """W:819-848.  Per replica: forward, backward, apply_gradients (all-reduce SUM, then
     Adam); returns ``strategy.reduce(SUM, per_replica_loss)`` as a 1-element device tensor.
     A replica whose slice of a short final batch is empty contributes zero gradients."""
     features, labels = dist_inputs
     strategy.begin_gradients(model.arena.g)
-    strategy.pre_launch = model._join_side  # weight gradients run on the model's second stream
+    # weight gradients run on the model's second stream: the exchange waits for it directly (the compute stream,
+    # busy with the dgrad chain, is not joined to it)
+    strategy.pre_launch, strategy.producers = None, model.gradient_streams
+    overlapped = ADAM_UNDER_BACKWARD and model.device.type == "cuda"
+    if overlapped:  # Adam slice by slice as buckets become final (and reduced), under the rest of backward
+        optimizer.begin_overlapped(model, strategy)
     if features.shape[0] > 0:
         loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready)
     else:
         # same reports as a real backward, so this rank's bucket launches match its peers' one for one
         model.report_zero_gradients(strategy.gradients_ready)
         loss = torch.zeros(1, dtype=torch.float32, device=model.device)
-    optimizer.apply_gradients(model, strategy)
+    if overlapped:
+        optimizer.finish_overlapped(model, strategy)
+    else:
+        optimizer.apply_gradients(model, strategy, zero_grad=True)
     return strategy.reduce_sum(loss.clone())
 
 
@@ -55,6 +71,7 @@ class GraphedTrainStep:
         self.labels.copy_(l)
         self._set_scalars(optimizer.iterations + 1)
         torch.cuda.synchronize()
+        model.arena.g_clean = False  # the captured step must contain its own fill of the gradient arena
         self._ws = model.ws  # the workspace set whose addresses the capture bakes in: keep it alive (model._ws_sets may evict it)
         self.graph = torch.cuda.CUDAGraph()
         m0 = (model.arena.p.clone(), model.arena.m.clone(), model.arena.v.clone())  # capture must not train
@@ -78,6 +95,7 @@ class GraphedTrainStep:
         self.opt.iterations += 1
         self._set_scalars(self.opt.iterations)
         self.graph.replay()
+        self.model.arena.g_clean = False  # the replayed step left its gradients in the arena
         return self.loss
 
 
@@ -272,7 +290,7 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
         model._prepare_clip()
         ops.segment_sumsq(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var)
         ops.segment_clip(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var, 1.0)
-    optimizer.apply_gradients(model, None)
+    optimizer.apply_gradients(model, None, zero_grad=True)
     model._pack_pos()
     return strategy.reduce_sum(loss.clone())
 
@@ -348,7 +366,7 @@ def single_train_step(model, audio, neg_indices_t, optimizer):
     (wav2vec2.sample_negative_indices_roll)."""
     model.neg_per_time = True
     loss = model.forward_backward(audio, neg_indices_t, num_replicas=1)
-    optimizer.apply_gradients(model, None)
+    optimizer.apply_gradients(model, None, zero_grad=True)
     model._pack_pos()
     return loss
 

@@ -328,7 +328,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         Hh = cfg.num_attention_heads
         hd = H // Hh
         sscale = 1.0 / math.sqrt(hd)
-        a.g.zero_()
+        if not getattr(a, "g_clean", False):
+            a.g.zero_()
+        a.g_clean = False
 
         # ---- feature encoder (V:283-288): conv -> GroupNorm -> GELU, 7 times
         in0 = ws["in0"]

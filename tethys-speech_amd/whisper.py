@@ -340,6 +340,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ``grad_ready`` range by range exactly as a real backward would."""
         a = self.arena
         a.g.zero_()
+        a.g_clean = False
         hi = a.numel
         for name in self.grad_ready_names():
             lo = a.offsets[name]
@@ -378,7 +379,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ws, a, d, ff = self.ws, self.arena, cfg.d_model, cfg.d_ff
         T, He, Hd = self.T, cfg.encoder_attention_heads, cfg.decoder_attention_heads
         scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
-        a.g.zero_()
+        if not getattr(a, "g_clean", False):
+            a.g.zero_()  # (an optimizer step with zero_grad leaves the arena clean: no fill pass)
+        a.g_clean = False
         done = [a.numel]
         expected = iter(self.grad_ready_names())
 
