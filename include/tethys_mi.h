@@ -85,6 +85,10 @@ typedef struct tmi_gemm_desc {
   int32_t splitk;
   int32_t in_dtype, out_dtype;
   void* workspace; int64_t workspace_bytes;
+  /* Dropout on the epilogue value, before the residual add (W:205: x + Dropout(fc2(..)); V:396, V:431):
+   * C = resid + (keep ? v / (1 - p) : 0) with the generator of tmi_dropout over the [M, N] output (counter m*N + n).
+   * dropout_p == 0 is off.  nbatch must be 1. */
+  float dropout_p; uint64_t dropout_seed;
 } tmi_gemm_desc;
 int tmi_gemm(const tmi_gemm_desc* d, void* stream);
 

@@ -354,6 +354,51 @@ def test_dropout_kernel_matches_host_generator(dev, dtype, with_resid, cols):
     assert torch.equal(g2, torch.where(keep, g.float() * DO.keep_scale(p), torch.zeros((), device=dev)).to(dtype))
 
 
+@pytest.mark.parametrize("M,N,K,variant", [(600, 768, 3072, "kc_ks"), (3000, 768, 768, "kc_ks"), (800, 3072, 768, "gelu"),
+                                             (300, 96, 64, "small"), (2100, 768, 1024, "kc_kc")])
+def test_gemm_epilogue_dropout_matches_host_generator(dev, M, N, K, variant):
+    """Dropout as a GEMM-epilogue term (tmi_gemm_desc.dropout_p; W:205 x + Dropout(fc2(g)), V:393 / V:396 / V:431): the
+    mask of tmi_dropout over the [M, N] output (oracle/dropout.py keep_flat), applied to the fp32 epilogue value after
+    bias / GELU / gelu' and before the residual add.  The shapes walk the kernels the step uses (eight-phase 256x256,
+    128x128, 64x64 tiles; k-strided and k-contiguous B)."""
+    from oracle import dropout as DO
+    ops = _ops()
+    bf = torch.bfloat16
+    p, seed = 0.1, 0x1234ABCD5678
+    A = rnd((M, K), bf, dev, 1, 0.5)
+    W = rnd((K, N), bf, dev, 2, 0.05)
+    bias = rnd((N,), torch.float32, dev, 3, 0.1)
+    resid = rnd((M, N), bf, dev, 4)
+    keep = torch.from_numpy(DO.keep_flat(seed, M, N, p)).to(dev)
+    base = A.float() @ W.float() + bias
+    out = torch.empty((M, N), dtype=bf, device=dev)
+    if variant == "gelu":      # act before the mask, saved pre-activation untouched
+        u = torch.empty_like(out)
+        ops.gemm(A, W, out, M, N, K, K, 1, N, 1, N, bias=bias, act=1, aux_out=u, dropout_p=p, dropout_seed=seed)
+        ref = torch.where(keep, torch.nn.functional.gelu(base) * DO.keep_scale(p), torch.zeros((), device=dev))
+        assert rel_err(u, base) <= 1e-2
+    elif variant == "kc_kc":   # dgrad form: B given k-contiguous ([N, K] rows), gelu' factor, then the mask
+        Wt = W.t().contiguous()
+        uu = rnd((M, N), bf, dev, 5)
+        ops.gemm(A, Wt, out, M, N, K, K, 1, 1, K, N, aux_in=uu, dropout_p=p, dropout_seed=seed)
+        x = uu.float()
+        gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * 3.141592653589793) ** 0.5
+        ref = torch.where(keep, (A.float() @ W.float()) * gp * DO.keep_scale(p), torch.zeros((), device=dev))
+        resid = None
+    else:
+        ops.gemm(A, W, out, M, N, K, K, 1, N, 1, N, bias=bias, resid=resid, r_ld=N, dropout_p=p, dropout_seed=seed)
+        ref = torch.where(keep, base * DO.keep_scale(p), torch.zeros((), device=dev)) + resid.float()
+    torch.cuda.synchronize()
+    if variant == "gelu":
+        resid = None
+    # dropped positions hold exactly the residual (or zero); kept ones the scaled value to bf16 accuracy
+    dropped = ~keep
+    want0 = resid.float() if resid is not None else torch.zeros((M, N), device=dev)
+    assert torch.equal(out.float()[dropped], want0.to(bf).float()[dropped])
+    assert rel_err(out, ref) <= 1.5e-2
+    assert abs(float(keep.float().mean()) - 0.9) < 5e-3
+
+
 # ----------------------------------------------------------------------------- embed / xent / adam / misc
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embedding(dev, dtype):

@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("splitk", c_i32),
         ("in_dtype", c_i32), ("out_dtype", c_i32),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
+        ("dropout_p", c_f32), ("dropout_seed", C.c_uint64),
     ]
 
 

@@ -265,7 +265,8 @@ class KernelBlocks:
         self._gemm_xw(x2d, wname, out2d, x2d.shape[0], N, K, x2d.stride(0), ldc=out2d.stride(0), n_off=n_off,
                       bias=bias, **epi)
 
-    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False):
+    def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False,
+                   dgrad_epi=None):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
         ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
         before its consumer), so the dgrad goes to the weight-gradient stream too."""
@@ -284,7 +285,7 @@ class KernelBlocks:
 
         def dgrad():
             ops.gemm(dy2d, w, dx2d, M, K_in, N, dy2d.stride(0), 1, 1, ldw, dx2d.stride(0),
-                     accumulate=accumulate_dx, aux_in=aux_in)
+                     accumulate=accumulate_dx, aux_in=aux_in, **(dgrad_epi or {}))
 
         if dgrad_on_side and dx2d is not None and self._side is not None:
             self._guard_write(dx2d)
@@ -332,6 +333,11 @@ class KernelBlocks:
         self._guard_write(out2d)
         ops.dropout(x2d, out2d, x2d.shape[0], x2d.shape[1], self._drop_p if p is None else p, self._site_seed(site),
                     resid=resid)
+
+    def _drop_epi(self, site, p=None):
+        """GEMM-epilogue form of ``_dropout`` (same generator, same counters): keyword arguments for ``ops.gemm``."""
+        p = self._drop_p if p is None else p
+        return {"dropout_p": p, "dropout_seed": self._site_seed(site)} if p > 0.0 else {}
 
     def _attn_fwd(self, key, q, k, v, ctx2d, B, H, Tq, Tk, mask, score_scale=1.0, site=None):
         """score_scale multiplies q·kᵀ (V:349); Whisper pre-scales q instead (W:141) and passes 1."""

@@ -5,6 +5,9 @@
 template <typename TC>
 __device__ __forceinline__ void gemm_epilogue(const tmi_gemm_desc& d, f32x16 (&acc)[2][2], int64_t m0, int64_t n0,
                                               int64_t bz, int wr, int wc, int lane, bool atomic) {
+  const uint32_t drop_thr = tmi_drop_thr(d.dropout_p);
+  const uint32_t drop_key = drop_thr ? tmi_stream_key(d.dropout_seed, 0u) : 0u;
+  const float drop_scale = tmi_keep_scale(drop_thr);
   TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb;
   TC* aux_out = d.aux_out ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb : nullptr;
   const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
@@ -33,6 +36,7 @@ __device__ __forceinline__ void gemm_epilogue(const tmi_gemm_desc& d, f32x16 (&a
         if (aux_out) aux_out[idx] = from_f32<TC>(v);
         if (d.act == 1) v = gelu_fwd_t<TC>(v);
         if (aux_in) v *= gelu_grad_t<TC>(to_f32(aux_in[idx]));
+        if (drop_thr) v = tmi_drop1(v, m, n, d.N, drop_key, drop_thr, drop_scale);
         if (resid) v += to_f32(resid[m * d.r_ld + n]);
         C[idx] = from_f32<TC>(v);
       }

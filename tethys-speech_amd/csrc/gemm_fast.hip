@@ -53,6 +53,8 @@ struct FastParams {
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
   int dbg;           // TMI_GEMM_DBG bit 1 (diagnostics only): skip the epilogue
+  uint32_t drop_thr, drop_key;  // epilogue dropout (desc.dropout_p): threshold (0 = off) and stream key
+  float drop_scale;
   int64_t split_c_stride;  // != 0: split s stores (no atomics) to C + s * split_c_stride (workspace slabs)
 };
 
@@ -286,6 +288,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
       }
+      if (P.drop_thr) tmi_drop8(v, m, n, d.N, P.drop_key, P.drop_thr, P.drop_scale);
       if (resid) {
         Vec8<TC>::load(resid + m * d.r_ld + n, t);
 #pragma unroll
@@ -301,6 +304,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
         if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
         if (d.act == 1) x = gelu_fwd_t<TC>(x);
         if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
+        if (P.drop_thr) x = tmi_drop1(x, m, n + i, d.N, P.drop_key, P.drop_thr, P.drop_scale);
         if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
         C[idx + i] = from_f32<TC>(x);
       }
@@ -371,6 +375,7 @@ __device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x1
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
       }
+      if (P.drop_thr) tmi_drop8(v, m, n, d.N, P.drop_key, P.drop_thr, P.drop_scale);
       if (resid) {
         Vec8<TC>::load(resid + m * d.r_ld + n, t);
 #pragma unroll
@@ -386,6 +391,7 @@ __device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x1
         if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
         if (d.act == 1) x = gelu_fwd_t<TC>(x);
         if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
+        if (P.drop_thr) x = tmi_drop1(x, m, n + i, d.N, P.drop_key, P.drop_thr, P.drop_scale);
         if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
         C[idx + i] = from_f32<TC>(x);
       }
@@ -961,6 +967,7 @@ int launch_with_slabs(const FastParams& P, int splitk, hipStream_t stream, F&& l
   Q.d.c_sb = d.M * d.N;
   Q.d.accumulate = 0;
   Q.split_c_stride = d.nbatch * d.M * d.N;
+  Q.drop_thr = 0;
   Q.wide = d.N % 4 == 0;
   launch(Q);
   int rc = tmi_check_launch("tmi_gemm(split-K)");
@@ -997,6 +1004,9 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
   P.split_c_stride = 0;
+  P.drop_thr = tmi_drop_thr(d.dropout_p);
+  P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
+  P.drop_scale = tmi_keep_scale(P.drop_thr);
   bool ws_split = false;
   auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && (CFG < 2 || CFG == 4 || CFG == 6)) {  // ablation builds exist for the bf16-out KC-A kernels only
@@ -1114,6 +1124,9 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg8 = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg8;
   P.split_c_stride = 0;
+  P.drop_thr = tmi_drop_thr(d.dropout_p);
+  P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
+  P.drop_scale = tmi_keep_scale(P.drop_thr);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
   if (attr != hipSuccess) {

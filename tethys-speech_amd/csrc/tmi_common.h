@@ -106,6 +106,21 @@ __host__ __device__ __forceinline__ bool tmi_keep(uint32_t key, uint64_t idx, ui
   return r >= thr;
 }
 
+// dropout term of a GEMM epilogue (tmi_gemm_desc.dropout_p): 8 consecutive columns n .. n+7 (n even) of output row m
+__device__ __forceinline__ void tmi_drop8(float (&v)[8], int64_t m, int64_t n, int64_t N, uint32_t key, uint32_t thr,
+                                          float scale) {
+  const uint32_t pid0 = (uint32_t)((m * N + n) >> 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t h = tmi_pair_hash(pid0 + j, key);
+    v[2 * j] = (h & 0xffffu) >= thr ? v[2 * j] * scale : 0.f;
+    v[2 * j + 1] = (h >> 16) >= thr ? v[2 * j + 1] * scale : 0.f;
+  }
+}
+__device__ __forceinline__ float tmi_drop1(float v, int64_t m, int64_t n, int64_t N, uint32_t key, uint32_t thr, float scale) {
+  return tmi_keep(key, (uint64_t)(m * N + n), thr) ? v * scale : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -393,22 +393,15 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             qkv = ws[kk + "qkv"]
             self._attn_fwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
                            ws[kk + "ctx"], B, Hh, T, T, 0, score_scale=sscale, site=SITE_ATTN + i)
-            if drop:  # V:431: x + Dropout(attention output)
-                self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws["dtmp"])
-                self._dropout(ws["dtmp"], ws[kk + "x_mid"], SITE_ATTN_OUT + i, resid=x_in)
-            else:
-                self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws[kk + "x_mid"], resid=x_in, r_ld=H)
+            # V:431: x + Dropout(attention output): the mask is a term of the GEMM epilogue
+            self._dense_fwd(ws[kk + "ctx"], p + ".attention.out_proj.kernel", ws[kk + "x_mid"], resid=x_in, r_ld=H,
+                            **self._drop_epi(SITE_ATTN_OUT + i))
             self._ln_fwd(ws[kk + "x_mid"], p + ".feed_forward_layer_norm", ws[kk + "xn2"], kk + "ln2")
             self._dense_fwd(ws[kk + "xn2"], p + ".feed_forward.intermediate_dense.kernel", ws[kk + "g"], act=1,
-                            aux_out=ws[kk + "u"])
-            if pa > 0.0:
-                self._dropout(ws[kk + "g"], ws[kk + "g"], SITE_FFN_MID + i, p=pa)  # V:393
+                            aux_out=ws[kk + "u"], **self._drop_epi(SITE_FFN_MID + i, p=pa))  # V:393 on the GELU output
             nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.num_hidden_layers else ws["enc_x"]
-            if drop:  # V:396
-                self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", ws["dtmp"])
-                self._dropout(ws["dtmp"], nxt, SITE_FFN_OUT + i, resid=ws[kk + "x_mid"])
-            else:
-                self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", nxt, resid=ws[kk + "x_mid"], r_ld=H)
+            self._dense_fwd(ws[kk + "g"], p + ".feed_forward.output_dense.kernel", nxt, resid=ws[kk + "x_mid"], r_ld=H,
+                            **self._drop_epi(SITE_FFN_OUT + i))  # V:396
 
         # ---- projection head + contrastive loss (V:550-561, V:866-899)
         pd = cfg.proj_codevector_dim
@@ -453,9 +446,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             if drop:  # the branch sees the masked gradient (same mask, regenerated)
                 dy = ws[f"dyd_f{i & 1}"]
                 self._dropout(dres, dy, SITE_FFN_OUT + i)
-            self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"])
-            if pa > 0.0:  # d gelu(u) = mask/keep * d g: the epilogue already multiplied by gelu'(u); elementwise factors commute
-                self._dropout(dU, dU, SITE_FFN_MID + i, p=pa)
+            # d u = gelu'(u) * mask/keep * d g: both factors are epilogue terms of the dgrad (elementwise factors commute)
+            self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"],
+                            dgrad_epi=self._drop_epi(SITE_FFN_MID + i, p=pa))
             self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_)
             self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True)
             dy = dres

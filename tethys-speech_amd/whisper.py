@@ -396,6 +396,52 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 grad_ready(lo, done[0])
                 done[0] = lo
 
+        drop = self._drop_p > 0.0
+        # The decoder's embedding and layer 0 up to its cross-attention query depend on the labels only: a chain of
+        # ~10 decoder-sized kernels that would otherwise sit, alone on the chip, between the encoder and the decoder.
+        # They run on the second stream beside the encoder's forward.
+        # decoder pieces (W:394-466); ids = [start, labels[:, :-1]] (W:559-563) inside the embedding kernel
+        kvc = ws["kvc_all"]
+        Ld = cfg.decoder_layers
+
+        def dec_embed():
+            y = ws["dec0.x_in"] if Ld else ws["dec_x"]
+            ops.embed_fwd(labels, a.param("decoder.embed_tokens.embeddings"), self.pe_dec, y, B, S, d,
+                          cfg.decoder_start_token_id)
+            if drop:
+                self._dropout(y, y, SITE_DEC_EMBED)  # W:411
+
+        def dec_self_block(i):
+            """Layer i up to the cross-attention query: needs nothing from the encoder."""
+            p, k = f"decoder.layers.{i}", f"dec{i}."
+            x_in = ws[k + "x_in"]
+            self._ln_fwd(x_in, p + ".self_attn_layer_norm", ws[k + "xn1"], k + "ln1")
+            self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_d)
+            qkv = ws[k + "qkv"]
+            self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
+                           ws[k + "ctx"], B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
+            self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
+            # cross attention (W:278-290): k/v projections of the encoder output in every layer
+            self._ln_fwd(ws[k + "x_mid"], p + ".encoder_attn_layer_norm", ws[k + "xn2"], k + "ln2")
+            self._dense_fwd(ws[k + "xn2"], p + ".encoder_attn.q_proj.kernel", ws[k + "qc"], scale_cols=d, scale=scal_d)
+
+        def dec_cross_ffn(i):
+            p, k = f"decoder.layers.{i}", f"dec{i}."
+            self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
+                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
+            self._dense_fwd(ws[k + "ctxc"], p + ".encoder_attn.out_proj.kernel", ws[k + "x_mid2"],
+                            resid=ws[k + "x_mid"], r_ld=d)
+            self._ln_fwd(ws[k + "x_mid2"], p + ".final_layer_norm", ws[k + "xn3"], k + "ln3")
+            self._dense_fwd(ws[k + "xn3"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
+            nxt = ws[f"dec{i + 1}.x_in"] if i + 1 < Ld else ws["dec_x"]
+            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid2"], r_ld=d,
+                            **self._drop_epi(SITE_DEC_FFN + i))
+
+        early_dec = self._side is not None and Ld > 0 and self._main is not None and os.environ.get("TMI_DEC_EARLY", "1") != "0"
+        early_ev = None
+        if early_dec:
+            self._run_on_side(lambda: (dec_embed(), dec_self_block(0)), labels)
+            early_ev = self._side_reads.pop(labels.data_ptr())
         # ---- encoder stem (W:329-339)
         xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
         ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
@@ -415,7 +461,6 @@ class WhisperForConditionalGeneration(KernelBlocks):
                       c_sb=T * d, bias=a.param("encoder.conv2.bias"), act=1, aux_out=ws["u2"], resid=self.pe_enc_t,
                       r_ld=d, r_sb=0)
 
-        drop = self._drop_p > 0.0
         if drop:
             self._dropout(x, x, SITE_ENC_STEM)  # W:342
         # ---- encoder layers (W:218-236)
@@ -431,49 +476,34 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._ln_fwd(ws[k + "x_mid"], p + ".final_layer_norm", ws[k + "xn2"], k + "ln2")
             self._dense_fwd(ws[k + "xn2"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
             nxt = ws[f"enc{i + 1}.x_in"] if i + 1 < cfg.encoder_layers else ws["enc_x"]
-            if drop:  # W:205: x_mid + Dropout(fc2(g))
-                tmp = ws["dtmp"][:B * T]
-                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", tmp)
-                self._dropout(tmp, nxt, SITE_ENC_FFN + i, resid=ws[k + "x_mid"])
-            else:
-                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid"], r_ld=d)
+            # W:205: x_mid + Dropout(fc2(g)): the mask is a term of the GEMM epilogue (before the residual add)
+            self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid"], r_ld=d,
+                            **self._drop_epi(SITE_ENC_FFN + i))
         self._ln_fwd(ws["enc_x"], "encoder.layer_norm", ws["enc_out"], "enc_ln")
         enc_out = ws["enc_out"]
 
-        # ---- decoder (W:394-466); ids = [start, labels[:, :-1]] (W:559-563) inside the kernel
-        y = ws["dec0.x_in"] if cfg.decoder_layers else ws["dec_x"]
-        ops.embed_fwd(labels, a.param("decoder.embed_tokens.embeddings"), self.pe_dec, y, B, S, d,
-                      cfg.decoder_start_token_id)
-        if drop:
-            self._dropout(y, y, SITE_DEC_EMBED)  # W:411
-        kvc = ws["kvc_all"]
-        if cfg.decoder_layers:  # W:122-123 for all layers at once (see the parameter spec)
-            self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc)
-        for i in range(cfg.decoder_layers):
-            p, k = f"decoder.layers.{i}", f"dec{i}."
-            x_in = ws[k + "x_in"]
-            self._ln_fwd(x_in, p + ".self_attn_layer_norm", ws[k + "xn1"], k + "ln1")
-            self._dense_fwd(ws[k + "xn1"], p + ".self_attn.qkv.kernel", ws[k + "qkv"], scale_cols=d, scale=scal_d)
-            qkv = ws[k + "qkv"]
-            self._attn_fwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
-                           ws[k + "ctx"], B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
-            self._dense_fwd(ws[k + "ctx"], p + ".self_attn.out_proj.kernel", ws[k + "x_mid"], resid=x_in, r_ld=d)
-            # cross attention (W:278-290): k/v projections of the encoder output in every layer
-            self._ln_fwd(ws[k + "x_mid"], p + ".encoder_attn_layer_norm", ws[k + "xn2"], k + "ln2")
-            self._dense_fwd(ws[k + "xn2"], p + ".encoder_attn.q_proj.kernel", ws[k + "qc"], scale_cols=d, scale=scal_d)
-            self._attn_fwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
-                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
-            self._dense_fwd(ws[k + "ctxc"], p + ".encoder_attn.out_proj.kernel", ws[k + "x_mid2"],
-                            resid=ws[k + "x_mid"], r_ld=d)
-            self._ln_fwd(ws[k + "x_mid2"], p + ".final_layer_norm", ws[k + "xn3"], k + "ln3")
-            self._dense_fwd(ws[k + "xn3"], p + ".feed_forward.fc1.kernel", ws[k + "g"], act=1, aux_out=ws[k + "u"])
-            nxt = ws[f"dec{i + 1}.x_in"] if i + 1 < cfg.decoder_layers else ws["dec_x"]
-            if drop:
-                tmp = ws["dtmp"][:B * S]
-                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", tmp)
-                self._dropout(tmp, nxt, SITE_DEC_FFN + i, resid=ws[k + "x_mid2"])
+        # ---- decoder (W:394-466)
+        if not early_dec:
+            dec_embed()
+        if Ld:
+            if self._side is not None and Ld > 1:
+                # W:122-123 for all layers: layer 0's k/v now (its cross-attention is next), the other layers' as ONE
+                # GEMM on the second stream under decoder layer 0's chain of small kernels
+                self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc, n_off=0, n_cols=2 * d)
+                self._run_on_side(lambda: self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc[:, 2 * d:], n_off=2 * d,
+                                                          n_cols=(Ld - 1) * 2 * d), enc_out)
+                kv_rest = self._side_reads.pop(enc_out.data_ptr())
             else:
-                self._dense_fwd(ws[k + "g"], p + ".feed_forward.fc2.kernel", nxt, resid=ws[k + "x_mid2"], r_ld=d)
+                self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc)
+                kv_rest = None
+        for i in range(Ld):
+            if not (early_dec and i == 0):
+                dec_self_block(i)
+            elif early_ev is not None:
+                self._main.wait_event(early_ev)  # layer 0's self-attention block ran beside the encoder
+            if i == 1 and kv_rest is not None:
+                self._main.wait_event(kv_rest)
+            dec_cross_ffn(i)
         self._ln_fwd(ws["dec_x"], "decoder.layer_norm", ws["dec_out"], "dec_ln")
 
         # ---- LM head + shifted cross-entropy (W:579-600); logits become dlogits in place
@@ -504,6 +534,15 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ready("decoder.layer_norm.gamma")
 
         d_enc, dkv = ws["d_enc_out"], ws["dkv_all"]
+        # (opt-in: measured slower on MI355X, 9.41 -> 9.73 ms/step - four K = 12000 weight gradients with their own
+        # split-K reductions cost more than the one fused GEMM saves by leaving the critical path)
+        kv_per_layer = (self._side is not None and cfg.decoder_layers > 1 and self._main is not None and
+                        os.environ.get("TMI_KV_PER_LAYER", "0") != "0")
+        if cfg.decoder_layers:
+            Lkv = cfg.decoder_layers * 2 * d
+            gkv = a.grad("decoder.cross_kv.kernel").view(d, Lkv)
+            gkvb = a.grad("decoder.cross_kv.bias")
+            wkv, ldkv = self.W("decoder.cross_kv.kernel")
         for i in reversed(range(cfg.decoder_layers)):
             p, k = f"decoder.layers.{i}", f"dec{i}."
             Rd = B * S
@@ -522,6 +561,18 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
                            (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctx, (dqc, 0),
                            (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
+            if kv_per_layer:
+                # this layer's dk / dv are final: its share of the cross-attention k/v projections' backward (weight
+                # and bias gradient, and d enc_out += dkv_i . Wkv_i^T) goes to the second stream now, under the chain of
+                # decoder-sized kernels that follows, instead of one K = L*2d GEMM alone on the chip after the loop
+                def kv_backward(i=i):
+                    lo = 2 * i * d
+                    ops.gemm(enc_out, dkv, gkv, d, 2 * d, B * T, 1, enc_out.stride(0), dkv.stride(0), 1, Lkv, splitk=0,
+                             b_off=lo, c_off=lo)
+                    ops.bias_grad(dkv[:, lo:lo + 2 * d], gkvb[lo:lo + 2 * d])
+                    ops.gemm(dkv, wkv, d_enc, B * T, d, 2 * d, dkv.stride(0), 1, 1, ldkv, d_enc.stride(0),
+                             accumulate=(i != cfg.decoder_layers - 1), a_off=lo, b_off=lo)
+                self._run_on_side(kv_backward, dkv[:, 2 * i * d:])
             dxn2 = ws["dctx"][:Rd]
             self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
             self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True)
@@ -534,9 +585,12 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
             ready(p + ".self_attn_layer_norm.gamma")
         if cfg.decoder_layers:
-            # every layer's dk / dv is in place: one weight gradient, one bias gradient and one dgrad
-            # (K = L*2d) for the cross-attention k/v projections of all layers
-            self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
+            if kv_per_layer:
+                self._main.wait_event(self._side_reads.pop(dkv.data_ptr()))  # d_enc is complete after layer 0's share
+            else:
+                # every layer's dk / dv is in place: one weight gradient, one bias gradient and one dgrad
+                # (K = L*2d) for the cross-attention k/v projections of all layers
+                self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
             ready("decoder.cross_kv.kernel")
         if drop:
             self._dropout(dres, dres, SITE_DEC_EMBED)
