@@ -217,6 +217,14 @@ int tmi_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr,
                   float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
                   float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
                   int32_t max_blocks, void* stream);
+/* The same update over an embedding table [nrows][row_len] (tf.keras.layers.Embedding, W:382), skipping idle rows:
+ * a row whose gradient is all zero and that has never been updated (active[r] == 0: m = v = 0) has an exactly-zero
+ * Adam update, so only its gradient is read.  active: one byte per row, zero-initialised by the caller and kept
+ * across steps (set by the kernel the first time a row sees a gradient).  weight_decay must be 0. */
+int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
+                       unsigned char* active, float lr, float beta1, float beta2, float eps,
+                       int32_t step, int32_t eps_mode, float weight_decay, float gscale,
+                       void* bf16_mirror, int32_t zero_grad, void* stream);
 /* The step-dependent scalars of tmi_adam_step, computed on the host exactly as it does:
  * out3 = {step_size, vcorr_inv_sqrt, 1 - lr*weight_decay}. */
 int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode,

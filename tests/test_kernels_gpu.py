@@ -399,6 +399,40 @@ def test_gemm_epilogue_dropout_matches_host_generator(dev, M, N, K, variant):
     assert abs(float(keep.float().mean()) - 0.9) < 5e-3
 
 
+def test_adam_rows_skips_idle_rows_and_matches_dense_bit_for_bit(dev):
+    """tmi_adam_step_rows over an embedding table (W:382): rows that never see a gradient are not touched, every other
+    row gets exactly the dense kernel's update - including rows whose gradient is zero in a later step (m, v decay)."""
+    ops = _ops()
+    rows, d = 300, 768
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(rows, d, generator=g).to(dev)
+    pa, pb = p0.clone(), p0.clone()
+    ma, va = torch.zeros_like(pa), torch.zeros_like(pa)
+    mb, vb = torch.zeros_like(pa), torch.zeros_like(pa)
+    mira, mirb = torch.zeros(rows, d, dtype=torch.bfloat16, device=dev), torch.zeros(rows, d, dtype=torch.bfloat16, device=dev)
+    mirb.copy_(p0)
+    mira.copy_(p0)
+    active = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    touched = set()
+    for step in range(1, 5):
+        idx = torch.randint(0, rows // 3, (40,), generator=g)  # only the first third of the table ever sees gradients
+        if step == 3:
+            idx = idx[:5]                                        # most earlier rows now have g = 0 but m, v != 0
+        touched |= set(idx.tolist())
+        gr = torch.zeros(rows, d)
+        gr[idx] = torch.randn(len(idx), d, generator=g)
+        ga, gb = gr.to(dev), gr.to(dev)
+        ops.adam_step(pa.view(-1), ga.view(-1), ma.view(-1), va.view(-1), rows * d, 1e-2, 0.9, 0.999, 1e-7, step, mirror=mira.view(-1),
+                      zero_grad=True)
+        ops.adam_step_rows(pb.view(-1), gb.view(-1), mb.view(-1), vb.view(-1), rows, d, active, 1e-2, 0.9, 0.999, 1e-7, step,
+                           mirror=mirb.view(-1), zero_grad=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(mira, mirb)
+        assert float(gb.abs().max()) == 0.0 and float(ga.abs().max()) == 0.0
+    assert set(torch.nonzero(active).flatten().tolist()) == touched
+    assert torch.equal(pb[rows // 3:], p0[rows // 3:])
+
+
 # ----------------------------------------------------------------------------- embed / xent / adam / misc
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_embedding(dev, dtype):

@@ -205,7 +205,88 @@ __global__ __launch_bounds__(256) void dropout_vec_kernel(const T* __restrict__ 
   }
 }
 
+// Row-sparse form for embedding tables (tf.keras.layers.Embedding, W:382): a row that has never received a gradient
+// has m = v = 0, and with g = 0 its Adam update is exactly zero (m, v stay 0; p -= step * 0 / (0 + eps)).  One wave per
+// row: read g; if the row is all zero and was never active, touch nothing else (4 of the 28-32 B/param); otherwise
+// update it and mark it active.  Bit-identical to the dense kernel on every row.
+template <bool ZG>
+__global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t nrows, int row_len,
+                                                        unsigned char* __restrict__ active, float b1, float b2, float eps,
+                                                        float step_size, float vcorr_inv_sqrt, int eps_mode, float decay,
+                                                        float gscale, bf16_t* __restrict__ mirror) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+  const int nvec = row_len >> 2;
+  for (int64_t r = wave; r < nrows; r += nwaves) {
+    const int64_t base = r * row_len;
+    bool any = false;
+    for (int i = lane; i < nvec; i += 64) {
+      const f32x4 gg = reinterpret_cast<const f32x4*>(g + base)[i];
+      any |= (gg[0] != 0.f) | (gg[1] != 0.f) | (gg[2] != 0.f) | (gg[3] != 0.f);
+    }
+    const bool live = __ballot(any) != 0ull;
+    const bool was = active[r] != 0;
+    if (!live && !was) continue;  // (wave-uniform)
+    if (live && !was && lane == 0) active[r] = 1;
+    for (int i = lane; i < nvec; i += 64) {
+      f32x4 pp = reinterpret_cast<f32x4*>(p + base)[i];
+      const f32x4 gg = reinterpret_cast<const f32x4*>(g + base)[i];
+      f32x4 mm = reinterpret_cast<f32x4*>(m + base)[i];
+      f32x4 vv = reinterpret_cast<f32x4*>(v + base)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = pp[j], b = mm[j], c = vv[j];
+        adam1(a, gg[j], b, c, b1, b2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale);
+        pp[j] = a; mm[j] = b; vv[j] = c;
+      }
+      reinterpret_cast<f32x4*>(p + base)[i] = pp;
+      reinterpret_cast<f32x4*>(m + base)[i] = mm;
+      reinterpret_cast<f32x4*>(v + base)[i] = vv;
+      if constexpr (ZG) reinterpret_cast<f32x4*>(g + base)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (mirror) {
+        bf16x4 sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[j] = (bf16_t)pp[j];
+        reinterpret_cast<bf16x4*>(mirror + base)[i] = sh;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
+                                  unsigned char* active, float lr, float beta1, float beta2, float eps, int32_t step,
+                                  int32_t eps_mode, float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
+                                  void* stream) {
+  if (!p || !g || !m || !v || !active || nrows <= 0 || row_len <= 0 || row_len % 4 || step <= 0 ||
+      (eps_mode != 0 && eps_mode != 1) || !al16(p) || !al16(g) || !al16(m) || !al16(v) ||
+      (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7)) || weight_decay != 0.f) {
+    tmi_set_error("tmi_adam_step_rows: bad argument (16-byte aligned arenas, row_len % 4 == 0, no weight decay: a decayed row is never idle)");
+    return TMI_ERR_INVALID;
+  }
+  const double c1 = 1.0 - pow((double)beta1, (double)step);
+  const double c2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size, vcorr_inv_sqrt;
+  if (eps_mode == 0) {
+    step_size = (float)((double)lr * sqrt(c2) / c1);
+    vcorr_inv_sqrt = 1.0f;
+  } else {
+    step_size = (float)((double)lr / c1);
+    vcorr_inv_sqrt = (float)(1.0 / sqrt(c2));
+  }
+  int64_t blocks = (nrows + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (zero_grad)
+    hipLaunchKernelGGL(adam_rows_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, nrows, (int)row_len, active,
+                       beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, 1.0f, gscale, (bf16_t*)bf16_mirror);
+  else
+    hipLaunchKernelGGL(adam_rows_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, nrows, (int)row_len, active,
+                       beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, 1.0f, gscale, (bf16_t*)bf16_mirror);
+  return tmi_check_launch("tmi_adam_step_rows");
+}
 
 extern "C" int tmi_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t step, int32_t eps_mode, float weight_decay,

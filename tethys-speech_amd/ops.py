@@ -287,6 +287,16 @@ def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_dec
                                   max_blocks, stream()), "tmi_adam_step")
 
 
+def adam_step_rows(p, g, m, v, nrows, row_len, active, lr, beta1, beta2, eps, step, eps_mode=0, gscale=1.0, mirror=None,
+                   zero_grad=False):
+    """Adam over an embedding table, idle rows skipped (tmi_adam_step_rows).  Algorithmic bytes as the dense kernel's
+    (the probe prices what a dense update would move)."""
+    with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * nrows * row_len):
+        check(lib().tmi_adam_step_rows(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), nrows, row_len,
+                                       active.data_ptr(), lr, beta1, beta2, eps, step, eps_mode, 0.0, gscale, ptr(mirror),
+                                       1 if zero_grad else 0, stream()), "tmi_adam_step_rows")
+
+
 def adam_scalars(lr, beta1, beta2, step, eps_mode=0, weight_decay=0.0):
     """[step_size, vcorr_inv_sqrt, decay] of one Adam step (host floats, as tmi_adam_step derives them)."""
     out = (C.c_float * 3)()

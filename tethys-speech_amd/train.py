@@ -72,6 +72,7 @@ class GraphedTrainStep:
         self._set_scalars(optimizer.iterations + 1)
         torch.cuda.synchronize()
         model.arena.g_clean = False  # the captured step must contain its own fill of the gradient arena
+        optimizer.row_sparse = False  # the captured update is the dense kernel: it does not keep the row-activity flags
         self._ws = model.ws  # the workspace set whose addresses the capture bakes in: keep it alive (model._ws_sets may evict it)
         self.graph = torch.cuda.CUDAGraph()
         m0 = (model.arena.p.clone(), model.arena.m.clone(), model.arena.v.clone())  # capture must not train

@@ -320,6 +320,13 @@ class WhisperForConditionalGeneration(KernelBlocks):
     # attention: q/k/v given as (tensor2d, column offset); rows are (b, t) with Tq / Tk per batch
 
 
+    def embedding_tables(self):
+        """(arena offset, rows, row length) of the tf.keras.layers.Embedding tables (W:382): rows that never see a
+        gradient are skipped by the optimizer (optim.Adam._update)."""
+        name = "decoder.embed_tokens.embeddings"
+        V, d = self.arena.shapes[name]
+        return [(self.arena.offsets[name], V, d)]
+
     def grad_ready_names(self) -> List[str]:
         """The parameters at which backward reports "everything stored at or after this one is final", in the
         order it reports them (arena order reversed).  The data-parallel strategy launches its buckets from

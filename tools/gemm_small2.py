@@ -1,0 +1,50 @@
+"""Decoder-sized GEMMs (M = B*100 = 800 rows) under the tile configurations tmi_gemm can be forced to
+(TMI_GEMM_CFG is read once per process: one child process per configuration)."""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1 and sys.argv[1] == "child":
+    sys.path.insert(0, ROOT)
+    import torch
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import ops
+    dev = "cuda:0"; bf = torch.bfloat16
+
+    def bench(fn, iters=100):
+        for _ in range(10): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+    out = []
+    M = 800
+    for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
+        X = torch.randn(M, K, device=dev).to(bf); Wt = torch.randn(N, K, device=dev).to(bf); W = torch.randn(K, N, device=dev).to(bf)
+        Y = torch.empty(M, N, device=dev, dtype=bf)
+        out.append((f"fwd  KC,KS M{M} N{N} K{K}", bench(lambda: ops.gemm(X, W, Y, M, N, K, K, 1, N, 1, N))))
+        out.append((f"dgrd KC,KC M{M} N{N} K{K}", bench(lambda: ops.gemm(X, Wt, Y, M, N, K, K, 1, 1, K, N))))
+    for Mo, No in ((768, 768), (768, 3072), (3072, 768), (768, 2304)):
+        X = torch.randn(M, Mo, device=dev).to(bf); DY = torch.randn(M, No, device=dev).to(bf)
+        G = torch.zeros(Mo, No, device=dev)
+        out.append((f"wgrd KS,KS out {Mo}x{No} K{M}", bench(lambda: ops.gemm(X, DY, G, Mo, No, M, 1, Mo, No, 1, No, splitk=0))))
+    for k, v in out:
+        print(f"{k:36s} {v:7.1f}")
+    sys.exit(0)
+res = {}
+cfgs = ["", "12", "13", "11", "6", "4"]
+for c in cfgs:
+    env = dict(os.environ)
+    if c:
+        env["TMI_GEMM_CFG"] = c
+    else:
+        env.pop("TMI_GEMM_CFG", None)
+    p = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
+    for line in p.stdout.splitlines():
+        if len(line) > 36 and line[36:].strip().replace(".", "").isdigit():
+            res.setdefault(line[:36], {})[c or "auto"] = float(line[36:])
+    if p.returncode:
+        print("cfg", c, "failed:", p.stderr[-300:])
+print(f"{'shape':36s} " + " ".join(f"{(c or 'auto'):>7s}" for c in cfgs) + "   (us; cfg 12 = 64x64 4 waves, 13 = + 4-stage ring, 11 = 2 waves ring, 6 = 2 waves, 4 = 128x128)")
+for k, v in res.items():
+    print(f"{k:36s} " + " ".join(f"{v.get(c or 'auto', float('nan')):7.1f}" for c in cfgs))
