@@ -312,6 +312,26 @@ int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx, void* q, 
 int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G,
                int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 
+/* First feature-encoder layer as a filter bank (V:283-288, i = 0: Conv1D(C, kernel 10, stride 5, "same", no bias) on
+ * the single-channel audio, then GroupNorm (V:140-196) and exact GELU), never materialising the conv output: both
+ * passes of the forward and both passes of the backward recompute it from the raw audio with the taps in registers.
+ *   audio fp32 [B][Tin] (batch stride a_sb); w fp32 [k][C] (the Keras kernel [k, 1, C]); T = ceil(Tin / stride) output
+ *   steps, pad_left = the "same" padding on the left; y / dy [B][T][C] of `dtype` with their own batch strides.
+ *   fwd: stats[B][G][2] = (mean, rstd) of u = conv(audio), y = gelu(gamma * xhat + beta).
+ *   bwd: dW[k][C] += d/dw, dgamma[C] += .., dbeta[C] += ..  (no input gradient: the input is data).
+ *   part: fp32 scratch of tmi_fir_chunks(T)*B*G*2 floats; sums: [B][G][2]; wpart: tmi_fir_gn_workspace_floats(). */
+int64_t tmi_fir_chunks(int64_t T);
+int64_t tmi_fir_gn_workspace_floats(int64_t B, int64_t T, int64_t C);
+int tmi_fir_groupnorm_gelu_fwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                               int64_t k, int64_t stride, const float* gamma, const float* beta, void* y,
+                               int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C,
+                               int64_t G, float eps, int32_t dtype, void* stream);
+int tmi_fir_groupnorm_gelu_bwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                               int64_t k, int64_t stride, const void* dy, int64_t dy_sb, const float* gamma,
+                               const float* beta, const float* stats, float* dW, float* dgamma, float* dbeta,
+                               float* part, float* sums, float* wpart, int64_t B, int64_t T, int64_t C,
+                               int64_t G, int32_t dtype, void* stream);
+
 /* Contrastive loss (V:866-899; whisper_single.py:745-787) on S [B][T][T] fp32 = all-pairs <h_t, q_t'>
  * (a tmi_gemm): row (b,t) has logits [S[t][t], S[t][idx[0..Nn)]] / temperature and label 0, where
  * idx = neg + b*neg_sb + t*neg_st (element strides): V:908-937 draws one row of indices per batch row

@@ -436,3 +436,51 @@ def test_whisper_single_base_golden_fp32(dev):
         got.append(float(loss.item()))
     rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
     assert max(rel) <= 2e-3, (rel, got, gold["losses"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Tin,C,G", [(2, 32000, 512, 16), (3, 4003, 128, 4), (1, 997, 256, 8)])
+def test_fir_conv0_groupnorm_gelu_fused(dev, dtype, B, Tin, C, G):
+    """Conv layer 0 as a filter bank fused with GroupNorm + GELU (tmi_fir_groupnorm_gelu_fwd / _bwd, V:283-288 with i = 0:
+    Conv1D(C, 10, stride 5, "same", no bias) on the raw audio) against the oracle's conv1d_same + group_norm + gelu and
+    their autograd gradients in fp64.  Ragged lengths exercise the "same" padding (left pad_total // 2) and the short last
+    chunk; y is written into a padded buffer with a row offset, as the model does."""
+    ops = _ops()
+    k, s = 10, 5
+    T, pl, pr = V.same_pad(Tin, k, s)
+    audio = rnd((B, Tin), torch.float32, dev, 40)
+    w = rnd((k, 1, C), torch.float32, dev, 41, 0.3)
+    gamma = rnd((C,), torch.float32, dev, 42, 0.2) + 1.0
+    beta = rnd((C,), torch.float32, dev, 43, 0.2)
+    pad = 1
+    y = torch.zeros((B, T + pad + 2, C), dtype=dtype, device=dev)
+    stats = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    part = torch.empty(B * ops.fir_chunks(T) * G * 2, dtype=torch.float32, device=dev)
+    ops.fir_groupnorm_gelu_fwd(audio, pl, w, k, s, gamma, beta, y, y.stride(0), stats, part, B, T, C, G, y_off=pad * C)
+    ar = audio.double().cpu()
+    wr = w.double().cpu().requires_grad_(True)
+    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    u = V.conv1d_same(ar.unsqueeze(-1), wr, None, s)
+    assert u.shape[1] == T
+    yr = O.gelu_erf(V.group_norm(u, gr, br, G))
+    assert rel_err(y[:, pad:pad + T], yr) <= (2e-5 if dtype == torch.float32 else 1.5e-2)
+    assert float(y[:, :pad].abs().max()) == 0.0 and float(y[:, pad + T:].abs().max()) == 0.0
+    ug = u.detach().reshape(B, T, G, C // G)
+    assert rel_err(stats[..., 0], ug.mean(dim=(1, 3))) <= 1e-4
+    dy = torch.zeros((B, T + 1, C), dtype=dtype, device=dev)
+    dy[:, 1:] = rnd((B, T, C), dtype, dev, 44)
+    yr.backward(dy[:, 1:].double().cpu())
+    dW = torch.zeros((k, 1, C), dtype=torch.float32, device=dev)
+    dg = torch.zeros(C, dtype=torch.float32, device=dev)
+    db = torch.zeros_like(dg)
+    sums = torch.empty((B, G, 2), dtype=torch.float32, device=dev)
+    wpart = torch.empty(ops.fir_gn_workspace_floats(B, T, C), dtype=torch.float32, device=dev)
+    ops.fir_groupnorm_gelu_bwd(audio, pl, w, k, s, dy, dy.stride(0), gamma, beta, stats, dW, dg, db, part, sums, wpart, B, T, C, G,
+                               dy_off=C)
+    torch.cuda.synchronize()
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert rel_err(dW, wr.grad) <= tol and rel_err(dg, gr.grad) <= tol and rel_err(db, br.grad) <= tol
+    # gradients ACCUMULATE into the arena slices (a second call doubles them)
+    ops.fir_groupnorm_gelu_bwd(audio, pl, w, k, s, dy, dy.stride(0), gamma, beta, stats, dW, dg, db, part, sums, wpart, B, T, C, G,
+                               dy_off=C)
+    assert rel_err(dW, 2 * wr.grad) <= tol

@@ -90,6 +90,12 @@ SIGNATURES = {
     "tmi_posconv_pack_weights": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_fir_chunks": (c_i64, [c_i64]),
+    "tmi_fir_gn_workspace_floats": (c_i64, [c_i64, c_i64, c_i64]),
+    "tmi_fir_groupnorm_gelu_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp,
+                                           c_i64, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_fir_groupnorm_gelu_bwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_grad_pack": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "tmi_grad_unpack": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp]),
     "tmi_contrastive_fwd_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp]),

@@ -234,6 +234,256 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------- conv layer 0 as an FIR, fused with GroupNorm + GELU
+// The first feature-encoder layer (V:283-288 with i = 0) is Conv1D(C, k = 10, stride 5, "same", no bias) on ONE input
+// channel: 2*k flop per output element against 2-4 bytes written - a filter bank, not a GEMM.  Its output u0
+// [B, T0, C] (52 MB at base size) is never materialised: the statistics pass, the apply pass and both backward passes
+// recompute it from the raw audio (a few hundred samples per workgroup, staged in LDS) with the k x C taps in registers.
+//   forward : stats (sum u, sum u^2 per (batch, group)) -> finalize -> y = gelu(gamma * xhat + beta)      [writes y only]
+//   backward: sums (sum dxhat, sum dxhat*xhat)          -> finalize -> du on the fly; dW[j][c] += in[S t + j - pl] * du,
+//             dgamma, dbeta                                                                  [reads dy twice, writes nothing big]
+// Thread layout as the GroupNorm kernels above: a thread owns 8 consecutive channels (one group), C/8 threads cover a
+// time step, 256/(C/8) time steps run in parallel, a workgroup walks a chunk of rows_per_chunk time steps.
+template <int KW>
+__device__ __forceinline__ void fir_load_taps(const float* __restrict__ w, int C, int c0, float (&tap)[KW][8]) {
+#pragma unroll
+  for (int j = 0; j < KW; ++j) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(w + (int64_t)j * C + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(w + (int64_t)j * C + c0 + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { tap[j][i] = a[i]; tap[j][4 + i] = b[i]; }
+  }
+}
+template <int KW>
+__device__ __forceinline__ void fir8(const float* __restrict__ win, const float (&tap)[KW][8], float (&u)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u[i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < KW; ++j) {
+    const float x = win[j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = fmaf(x, tap[j][i], u[i]);
+  }
+}
+// stage audio samples [r0*S - pl, r0*S - pl + n) of batch row `a` (zeros outside [0, Tin)) into LDS
+__device__ __forceinline__ void fir_stage(float* win, const float* __restrict__ a, int64_t first, int n, int Tin) {
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int64_t idx = first + i;
+    win[i] = (idx >= 0 && idx < Tin) ? a[idx] : 0.f;
+  }
+}
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  bf16x8 a;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+  *reinterpret_cast<bf16x8*>(p) = a;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// MODE 0: a = sum u, b = sum u^2;  MODE 1: a = sum dz*gamma, b = sum dz*gamma*xhat (dz = dy * gelu'(z))
+template <typename T, int KW, int S, int MODE>
+__global__ __launch_bounds__(256) void fir_gn_partial_kernel(const float* __restrict__ audio, int64_t asb, int Tin, int pl,
+                                                             const float* __restrict__ w, const T* __restrict__ dy,
+                                                             int64_t dysb, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ stats,
+                                                             float* __restrict__ part, int Tn, int C, int G,
+                                                             int rows_per_chunk, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* win = reinterpret_cast<float*>(smem);  // [rows_per_chunk * S + KW]
+  __shared__ float sa[256], sb[256];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int Cg = C / G, cpr = C / 8;
+  const int c0 = (threadIdx.x % cpr) * 8, g = c0 / Cg;
+  const int rstep = 256 / cpr;
+  const int r0 = chunk * rows_per_chunk, r1 = min(Tn, r0 + rows_per_chunk);
+  float tap[KW][8];
+  fir_load_taps<KW>(w, C, c0, tap);
+  fir_stage(win, audio + (int64_t)b * asb, (int64_t)r0 * S - pl, (r1 - r0) * S + KW, Tin);
+  float gm[8], bt[8], mean = 0.f, rstd = 0.f;
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
+    mean = stats[(b * G + g) * 2];
+    rstd = stats[(b * G + g) * 2 + 1];
+  }
+  __syncthreads();
+  float a = 0.f, bsum = 0.f;
+  for (int r = r0 + threadIdx.x / cpr; r < r1; r += rstep) {
+    float u[8];
+    fir8<KW>(win + (r - r0) * S, tap, u);
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { a += u[i]; bsum += u[i] * u[i]; }
+    } else {
+      float d[8];
+      load8<T>(dy + (int64_t)b * dysb + (int64_t)r * C + c0, d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float xh = (u[i] - mean) * rstd;
+        const float dz = d[i] * gelu_grad_t<T>(gm[i] * xh + bt[i]);
+        a += dz * gm[i];
+        bsum += dz * gm[i] * xh;
+      }
+    }
+  }
+  sa[threadIdx.x] = a;
+  sb[threadIdx.x] = bsum;
+  __syncthreads();
+  if (threadIdx.x < cpr) {
+    float ta = sa[threadIdx.x], tb = sb[threadIdx.x];
+    for (int k = 1; k < rstep; ++k) { ta += sa[threadIdx.x + k * cpr]; tb += sb[threadIdx.x + k * cpr]; }
+    sa[threadIdx.x] = ta;
+    sb[threadIdx.x] = tb;
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    const int per = Cg / 8;
+    float ta = 0.f, tb = 0.f;
+    for (int t = 0; t < per; ++t) { ta += sa[threadIdx.x * per + t]; tb += sb[threadIdx.x * per + t]; }
+    float* o = part + (((int64_t)b * nchunks + chunk) * G + threadIdx.x) * 2;
+    o[0] = ta;
+    o[1] = tb;
+  }
+}
+
+template <typename T, int KW, int S>
+__global__ __launch_bounds__(256) void fir_gn_apply_fwd_kernel(const float* __restrict__ audio, int64_t asb, int Tin, int pl,
+                                                               const float* __restrict__ w, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ stats,
+                                                               T* __restrict__ y, int64_t ysb, int Tn, int C, int G,
+                                                               int rows_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* win = reinterpret_cast<float*>(smem);
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int Cg = C / G, cpr = C / 8;
+  const int c0 = (threadIdx.x % cpr) * 8, g = c0 / Cg;
+  const int rstep = 256 / cpr;
+  const int r0 = chunk * rows_per_chunk, r1 = min(Tn, r0 + rows_per_chunk);
+  float tap[KW][8];
+  fir_load_taps<KW>(w, C, c0, tap);
+  fir_stage(win, audio + (int64_t)b * asb, (int64_t)r0 * S - pl, (r1 - r0) * S + KW, Tin);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  __syncthreads();
+  for (int r = r0 + threadIdx.x / cpr; r < r1; r += rstep) {
+    float u[8];
+    fir8<KW>(win + (r - r0) * S, tap, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u[i] = gelu_fwd_t<T>(gm[i] * ((u[i] - mean) * rstd) + bt[i]);
+    store8<T>(y + (int64_t)b * ysb + (int64_t)r * C + c0, u);
+  }
+}
+
+// backward apply: du = rstd * (dz*gamma - m1 - xhat*m2) stays in registers; per-workgroup partial sums of
+// dW [KW][C], dgamma [C], dbeta [C] go to wpart[(b*nchunks + chunk)][(KW + 2) * C] (summed by fir_reduce_kernel)
+template <typename T, int KW, int S>
+__global__ __launch_bounds__(256) void fir_gn_apply_bwd_kernel(const float* __restrict__ audio, int64_t asb, int Tin, int pl,
+                                                               const float* __restrict__ w, const T* __restrict__ dy,
+                                                               int64_t dysb, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ stats,
+                                                               const float* __restrict__ sums, float* __restrict__ wpart,
+                                                               int Tn, int C, int G, int rows_per_chunk, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* win = reinterpret_cast<float*>(smem);                       // [rows_per_chunk * S + KW]
+  float* red = win + ((rows_per_chunk * S + KW + 3) & ~3);           // [rstep][C] fold buffer
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int Cg = C / G, cpr = C / 8;
+  const int c0 = (threadIdx.x % cpr) * 8, g = c0 / Cg;
+  const int rstep = 256 / cpr, rl = threadIdx.x / cpr;
+  const int r0 = chunk * rows_per_chunk, r1 = min(Tn, r0 + rows_per_chunk);
+  float tap[KW][8], acc[KW + 2][8];
+  fir_load_taps<KW>(w, C, c0, tap);
+  fir_stage(win, audio + (int64_t)b * asb, (int64_t)r0 * S - pl, (r1 - r0) * S + KW, Tin);
+  float gm[8], bt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
+#pragma unroll
+  for (int j = 0; j < KW + 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float m1 = sums[(b * G + g) * 2], m2 = sums[(b * G + g) * 2 + 1];
+  __syncthreads();
+  for (int r = r0 + rl; r < r1; r += rstep) {
+    const float* wr = win + (r - r0) * S;
+    float u[8], d[8];
+    fir8<KW>(wr, tap, u);
+    load8<T>(dy + (int64_t)b * dysb + (int64_t)r * C + c0, d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float xh = (u[i] - mean) * rstd;
+      const float dz = d[i] * gelu_grad_t<T>(gm[i] * xh + bt[i]);
+      acc[KW][i] += dz * xh;   // dgamma
+      acc[KW + 1][i] += dz;    // dbeta
+      u[i] = rstd * (dz * gm[i] - m1 - xh * m2);  // du
+    }
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      const float x = wr[j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[j][i] = fmaf(x, u[i], acc[j][i]);
+    }
+  }
+  // fold the rstep row lanes, one quantity at a time, in a fixed order
+  float* out = wpart + ((int64_t)b * nchunks + chunk) * (int64_t)(KW + 2) * C;
+  for (int j = 0; j < KW + 2; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < KW + 2; ++jj) v = jj == j ? acc[jj][i] : v;  // (static indexing keeps acc in registers)
+      red[rl * C + c0 + i] = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t = 0.f;
+      for (int k = 0; k < rstep; ++k) t += red[k * C + c];
+      out[j * C + c] = t;
+    }
+  }
+}
+
+// dst[i] += sum over the partial rows of src[p][i]  (dW, dgamma, dbeta of the FIR layer): blockIdx.y takes every
+// gridDim.y-th partial row, eight loads in flight per thread, one atomic per element per y-slice
+__global__ __launch_bounds__(256) void fir_reduce_kernel(const float* __restrict__ src, int nparts, int64_t len_w,
+                                                         int64_t C, float* __restrict__ dW, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta) {
+  const int64_t len = len_w + 2 * C;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= len) return;
+  float t = 0.f;
+  int p = blockIdx.y;
+  const int ps = gridDim.y;
+  for (; p + 7 * ps < nparts; p += 8 * ps) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(p + u * ps) * len + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += v[u];
+  }
+  for (; p < nparts; p += ps) t += src[(int64_t)p * len + i];
+  float* dst = i < len_w ? dW + i : (i < len_w + C ? dgamma + (i - len_w) : dbeta + (i - len_w - C));
+  atomicAdd(dst, t);
+}
+
 // ---------------------------------------------------------------- grouped pos-conv layout packs
 // x [R][C] (rows r < R_valid come from the source, others are zero) -> xg [G][R][Cg]
 template <typename T>
@@ -558,6 +808,85 @@ extern "C" int tmi_groupnorm_gelu_bwd(const void* x, int64_t x_sb, const void* d
              hipLaunchKernelGGL(gn_apply_bwd_kernel<bf16_t>, gp, dim3(256), lds, s, (const bf16_t*)x, x_sb, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, (bf16_t*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc),
              hipLaunchKernelGGL(gn_apply_bwd_kernel<float>, gp, dim3(256), lds, s, (const float*)x, x_sb, (const float*)dy, dy_sb, gamma, beta, stats, sums, (float*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc));
   return tmi_check_launch("tmi_groupnorm_gelu_bwd");
+}
+
+// ---- conv layer 0 as an FIR fused with GroupNorm + GELU (see the kernels above)
+static int fir_check(const float* audio, const float* w, int64_t B, int64_t Tin, int64_t T, int64_t C, int64_t G, int64_t k,
+                     int64_t stride) {
+  return audio && w && B > 0 && B <= 65535 && Tin > 0 && T > 0 && C > 0 && C <= 2048 && C % 8 == 0 && 2048 % C == 0 && G > 0 &&
+         G <= 256 && C % G == 0 && (C / G) % 8 == 0 && k == 10 && stride == 5 && al16(w);
+}
+// chunks per sample of the FIR kernels: ~100 time steps each (the kernels are VALU-bound: several waves per SIMD)
+extern "C" int64_t tmi_fir_chunks(int64_t T) {
+  int64_t n = (T + 99) / 100;
+  if (n > 64) n = 64;
+  return n < 1 ? 1 : n;
+}
+extern "C" int64_t tmi_fir_gn_workspace_floats(int64_t B, int64_t T, int64_t C) {
+  return B * tmi_fir_chunks(T) * 12 * C;  // per-workgroup partials of dW (10 x C), dgamma, dbeta
+}
+
+extern "C" int tmi_fir_groupnorm_gelu_fwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const float* gamma, const float* beta, void* y,
+                                          int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          float eps, int32_t dtype, void* stream) {
+  if (!fir_check(audio, w, B, Tin, T, C, G, k, stride) || !gamma || !beta || !y || !stats || !part || !al16(y) || y_sb % 8 ||
+      pad_left < 0) {
+    tmi_set_error("tmi_fir_groupnorm_gelu_fwd: bad argument (kernel 10, stride 5, C % 8 == 0, 2048 % C == 0, (C/G) % 8 == 0)");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nch = (int)tmi_fir_chunks(T);
+  const int rpc = (int)((T + nch - 1) / nch);
+  const size_t lds = (size_t)(rpc * 5 + 10) * sizeof(float);
+  dim3 gp((unsigned)nch, (unsigned)B);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((fir_gn_partial_kernel<bf16_t, 10, 5, 0>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
+             hipLaunchKernelGGL((fir_gn_partial_kernel<float, 10, 5, 0>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, stats, (int)(B * G), (int)G, nch,
+                     (double)T * (double)(C / G), eps, 0);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<bf16_t, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (bf16_t*)y, y_sb, (int)T, (int)C, (int)G, rpc),
+             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<float, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (float*)y, y_sb, (int)T, (int)C, (int)G, rpc));
+  return tmi_check_launch("tmi_fir_groupnorm_gelu_fwd");
+}
+
+extern "C" int tmi_fir_groupnorm_gelu_bwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const void* dy, int64_t dy_sb, const float* gamma,
+                                          const float* beta, const float* stats, float* dW, float* dgamma, float* dbeta,
+                                          float* part, float* sums, float* wpart, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          int32_t dtype, void* stream) {
+  if (!fir_check(audio, w, B, Tin, T, C, G, k, stride) || !dy || !gamma || !beta || !stats || !dW || !dgamma || !dbeta ||
+      !part || !sums || !wpart || !al16(dy) || dy_sb % 8 || pad_left < 0) {
+    tmi_set_error("tmi_fir_groupnorm_gelu_bwd: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int nch = (int)tmi_fir_chunks(T);
+  const int rpc = (int)((T + nch - 1) / nch);
+  const int nwin = rpc * 5 + 10;
+  const size_t lds = (size_t)nwin * sizeof(float);
+  dim3 gp((unsigned)nch, (unsigned)B);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((fir_gn_partial_kernel<bf16_t, 10, 5, 1>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
+             hipLaunchKernelGGL((fir_gn_partial_kernel<float, 10, 5, 1>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, sums, (int)(B * G), (int)G, nch,
+                     (double)T * (double)(C / G), 0.f, 1);
+  // the apply pass ends with a 12-quantity fold per workgroup and holds 256 registers: coarser chunks (one workgroup
+  // per CU at base size) measured faster than the finer ones the other passes use (71 vs 84 us)
+  const int nchA = (int)tmi_groupnorm_chunks(T);
+  const int rpcA = (int)((T + nchA - 1) / nchA);
+  const int nwinA = rpcA * 5 + 10;
+  dim3 gpA((unsigned)nchA, (unsigned)B);
+  const int rstep = 256 / (int)(C / 8);
+  const size_t lds2 = (size_t)(((nwinA + 3) & ~3) + rstep * C) * sizeof(float);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<bf16_t, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA),
+             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<float, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA));
+  const int64_t rb = (12 * C + 255) / 256;
+  const int64_t ry = B * nchA >= 64 ? 8 : 1;
+  hipLaunchKernelGGL(fir_reduce_kernel, dim3((unsigned)rb, (unsigned)ry), dim3(256), 0, s, wpart, (int)(B * nchA), (int64_t)10 * C, C, dW, dgamma, dbeta);
+  return tmi_check_launch("tmi_fir_groupnorm_gelu_bwd");
 }
 
 extern "C" int tmi_group_pack(const void* x, void* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t Tp,

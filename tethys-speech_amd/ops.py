@@ -372,6 +372,34 @@ def groupnorm_gelu_bwd(x, x_sb, dy, dy_sb, gamma, beta, stats, dx, dx_sb, dgamma
           "tmi_groupnorm_gelu_bwd")
 
 
+def fir_chunks(T: int) -> int:
+    return int(lib().tmi_fir_chunks(T))
+
+
+def fir_gn_workspace_floats(B, T, Cn):
+    return int(lib().tmi_fir_gn_workspace_floats(B, T, Cn))
+
+
+def fir_groupnorm_gelu_fwd(audio, pad_left, w, k, stride, gamma, beta, y, y_sb, stats, part, B, T, Cn, G, eps=1e-5, y_off=0):
+    """Conv layer 0 as a filter bank + GroupNorm + GELU (tmi_fir_groupnorm_gelu_fwd): audio fp32 [B, Tin]."""
+    # algorithmic bytes: the output written once (the audio is ~1/250 of it)
+    with _probe("groupnorm", 1.0 * B * T * Cn * y.element_size()):
+        check(lib().tmi_fir_groupnorm_gelu_fwd(audio.data_ptr(), audio.stride(0), audio.shape[1], pad_left, w.data_ptr(), k, stride,
+                                               gamma.data_ptr(), beta.data_ptr(), y.data_ptr() + y_off * y.element_size(), y_sb,
+                                               stats.data_ptr(), part.data_ptr(), B, T, Cn, G, eps, dt(y), stream()),
+              "tmi_fir_groupnorm_gelu_fwd")
+
+
+def fir_groupnorm_gelu_bwd(audio, pad_left, w, k, stride, dy, dy_sb, gamma, beta, stats, dW, dgamma, dbeta, part, sums, wpart,
+                           B, T, Cn, G, dy_off=0):
+    with _probe("groupnorm", 2.0 * B * T * Cn * dy.element_size()):  # dy read by both passes
+        check(lib().tmi_fir_groupnorm_gelu_bwd(audio.data_ptr(), audio.stride(0), audio.shape[1], pad_left, w.data_ptr(), k, stride,
+                                               dy.data_ptr() + dy_off * dy.element_size(), dy_sb, gamma.data_ptr(), beta.data_ptr(),
+                                               stats.data_ptr(), dW.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               part.data_ptr(), sums.data_ptr(), wpart.data_ptr(), B, T, Cn, G, dt(dy), stream()),
+              "tmi_fir_groupnorm_gelu_bwd")
+
+
 def group_pack(x, xg, B, T, Cn, G, Tp, pad_left):
     check(lib().tmi_group_pack(x.data_ptr(), xg.data_ptr(), B, T, Cn, G, Tp, pad_left, dt(x), stream()), "tmi_group_pack")
 

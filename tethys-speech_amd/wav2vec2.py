@@ -222,11 +222,20 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         z = dict(zero=True)
         # input of conv layer i (padded, channels-last): i = 0 is the audio itself (C = 1)
         self.Tp = [([T_in] + self.lens)[i] + self.pads[i][0] + self.pads[i][1] for i in range(L)]
-        self._buf("in0", (B, self.Tp[0] + slack + 8, 1), **z)
+        # conv layer 0 runs as a filter bank fused with its GroupNorm + GELU straight from the audio (tmi_fir_groupnorm_gelu_*)
+        # whenever the reference's first-layer geometry holds (kernel 10, stride 5: every size of V:24-128)
+        c0_ = cfg.conv_dim[0]
+        self.fir0 = (cfg.conv_kernel[0] == 10 and cfg.conv_stride[0] == 5 and c0_ % 8 == 0 and 2048 % c0_ == 0 and
+                     (c0_ // Gn) % 8 == 0 and os.environ.get("TMI_W2V_FIR", "1") != "0")
+        if not self.fir0:
+            self._buf("in0", (B, self.Tp[0] + slack + 8, 1), **z)
+        else:
+            self._buf("fir_wpart", (ops.fir_gn_workspace_floats(B, self.lens[0], c0_),), f32)
         cin = 1
         for i in range(L):
             c = cfg.conv_dim[i]
-            self._buf(f"u{i}", (B, self.lens[i], c))
+            if not (i == 0 and self.fir0):
+                self._buf(f"u{i}", (B, self.lens[i], c))
             self._buf(f"gn{i}.stats", (B, Gn, 2), f32)
             if i + 1 < L:
                 self._buf(f"in{i + 1}", (B, self.Tp[i + 1] + slack, c), **z)
@@ -292,7 +301,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._buf("dP", (B, cfg.num_attention_heads, self.T, self.T), f32)
         maxrows = max(1 + t for t in self.lens)
         self._buf("dupad", (B * maxrows * max(cfg.conv_dim),), **z)
-        nch = max(ops.groupnorm_chunks(t) for t in self.lens)
+        nch = max([ops.groupnorm_chunks(t) for t in self.lens] + ([ops.fir_chunks(self.lens[0])] if self.fir0 else []))
         self._buf("gn_part", (B * nch * Gn * 2,), f32)
         self._buf("gn_sums", (B, Gn, 2), f32)
         self._buf("clip_all", (1,), f32)
@@ -333,19 +342,27 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         a.g_clean = False
 
         # ---- feature encoder (V:283-288): conv -> GroupNorm -> GELU, 7 times
-        in0 = ws["in0"]
-        ops.feat_to_channels_last(audio, in0, B, 1, T_in, self.pads[0][0], in0.shape[1] - T_in - self.pads[0][0])
+        if not self.fir0:
+            in0 = ws["in0"]
+            ops.feat_to_channels_last(audio, in0, B, 1, T_in, self.pads[0][0], in0.shape[1] - T_in - self.pads[0][0])
         cin = 1
         for i in range(L):
             c, k, s = cfg.conv_dim[i], cfg.conv_kernel[i], cfg.conv_stride[i]
-            xin, u = ws[f"in{i}"], ws[f"u{i}"]
-            self._gemm_xw(xin, f"feature_extractor.conv_layers.{i}.conv.kernel", u, self.lens[i], c, k * cin, s * cin,
-                          ldc=c, nbatch=B, a_sb=xin.stride(0), c_sb=u.stride(0))
             pre = f"feature_extractor.conv_layers.{i}.norm"
             if i + 1 < L:
                 y, ysb, yoff = ws[f"in{i + 1}"], ws[f"in{i + 1}"].stride(0), self.pads[i + 1][0] * c
             else:
                 y, ysb, yoff = ws["h_last"], self.lens[i] * c, 0
+            if i == 0 and self.fir0:
+                # C_in = 1: a filter bank, fused with GroupNorm + GELU, its output never written (fp32 master taps)
+                ops.fir_groupnorm_gelu_fwd(audio, self.pads[0][0], a.param("feature_extractor.conv_layers.0.conv.kernel"), k, s,
+                                           a.param(pre + ".gamma"), a.param(pre + ".beta"), y, ysb, ws["gn0.stats"],
+                                           ws["gn_part"], B, self.lens[0], c, Gn, 1e-5, y_off=yoff)
+                cin = c
+                continue
+            xin, u = ws[f"in{i}"], ws[f"u{i}"]
+            self._gemm_xw(xin, f"feature_extractor.conv_layers.{i}.conv.kernel", u, self.lens[i], c, k * cin, s * cin,
+                          ldc=c, nbatch=B, a_sb=xin.stride(0), c_sb=u.stride(0))
             ops.groupnorm_gelu_fwd(u, u.stride(0), a.param(pre + ".gamma"), a.param(pre + ".beta"), y, ysb,
                                    ws[f"gn{i}.stats"], ws["gn_part"], B, self.lens[i], c, Gn, 1e-5, y_off=yoff)
             cin = c
@@ -502,11 +519,18 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             cin = cfg.conv_dim[i - 1] if i else 1
             Ti = self.lens[i]
             pre = f"feature_extractor.conv_layers.{i}.norm"
-            u = ws[f"u{i}"]
             if i + 1 < L:
                 dy, dysb, dyoff = ws[f"din{i + 1}"], ws[f"din{i + 1}"].stride(0), self.pads[i + 1][0] * c
             else:
                 dy, dysb, dyoff = ws["dh_last"], Ti * c, 0
+            if i == 0 and self.fir0:
+                wname0 = "feature_extractor.conv_layers.0.conv.kernel"
+                ops.fir_groupnorm_gelu_bwd(audio, self.pads[0][0], a.param(wname0), kc, s, dy, dysb, a.param(pre + ".gamma"),
+                                           a.param(pre + ".beta"), ws["gn0.stats"], a.grad(wname0), a.grad(pre + ".gamma"),
+                                           a.grad(pre + ".beta"), ws["gn_part"], ws["gn_sums"], ws["fir_wpart"], B, Ti, c, Gn,
+                                           dy_off=dyoff)
+                continue
+            u = ws[f"u{i}"]
             dup = ws["dupad"][:B * (1 + Ti) * c].view(B, 1 + Ti, c)  # row 0 of every batch stays zero
             dup[:, 0].zero_()
             ops.groupnorm_gelu_bwd(u, u.stride(0), dy, dysb, a.param(pre + ".gamma"), a.param(pre + ".beta"),
