@@ -225,6 +225,17 @@ int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_t nrows, in
                        unsigned char* active, float lr, float beta1, float beta2, float eps,
                        int32_t step, int32_t eps_mode, float weight_decay, float gscale,
                        void* bf16_mirror, int32_t zero_grad, void* stream);
+/* tmi_adam_step over the reference's variables (chunks: int64 device array [nchunks][3] = (first element, end element,
+ * variable index) tiling the arena in pieces that never cross a variable; sumsq indexed by variable) with the gradient clipping of V:1243 (tf.clip_by_global_norm, before the update) and V:1274 (Keras
+ * clipnorm = tf.clip_by_norm per variable) applied as a per-variable factor of g, computed from ONE
+ * tmi_segment_sumsq pass over the raw gradients (sumsq[nseg]):
+ *   c_g = clip_global / max(||g||, clip_global),  c_s = clip_each / max(c_g * ||g_s||, clip_each),  g' = g * gscale * c_g * c_s
+ * (clip_global == 0 / clip_each == 0 switch a stage off).  No clipped copy of the gradients is written. */
+int tmi_adam_step_segments(float* p, float* g, float* m, float* v, const int64_t* chunks,
+                           int64_t nchunks, const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr,
+                           float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
+                           float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
+                           void* stream);
 /* The step-dependent scalars of tmi_adam_step, computed on the host exactly as it does:
  * out3 = {step_size, vcorr_inv_sqrt, 1 - lr*weight_decay}. */
 int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode,

@@ -175,6 +175,44 @@ def test_segment_clip(dev):
     assert abs(float(ss[0]) - float((g0.double() ** 2).sum())) <= 1e-4 * float((g0.double() ** 2).sum())
 
 
+@pytest.mark.parametrize("clip_global,clip_each", [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0)])
+def test_adam_with_clipping_folded_in(dev, clip_global, clip_each):
+    """tmi_adam_step_segments: tf.clip_by_global_norm (V:1243) and Keras clipnorm (V:1274) as per-variable factors of g
+    inside the Adam launch == materialising both clips (tmi_segment_clip twice) and then the plain Adam launch."""
+    ops = _ops()
+    n = 20000
+    offs_l = [0, 104, 4000, 4008, 12000, 20000]
+    offs = torch.tensor(offs_l, dtype=torch.int64, device=dev)
+    nseg = len(offs_l) - 1
+    one = torch.tensor([0, n], dtype=torch.int64, device=dev)
+    p0 = rnd((n,), torch.float32, dev, 50)
+    g0 = rnd((n,), torch.float32, dev, 51, 0.05)
+    g0[4008:12000] *= 1e-3  # a variable below the clip threshold
+    m0 = rnd((n,), torch.float32, dev, 52, 0.01)
+    v0 = rnd((n,), torch.float32, dev, 53, 0.01).abs()
+    # reference path: two clip passes, then Adam
+    pr, gr, mr, vr = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    ss = torch.empty(nseg, dtype=torch.float32, device=dev)
+    if clip_global > 0:
+        ops.segment_sumsq(gr, one, ss, 1)
+        ops.segment_clip(gr, one, ss, 1, clip_global)
+    if clip_each > 0:
+        ops.segment_sumsq(gr, offs, ss, nseg)
+        ops.segment_clip(gr, offs, ss, nseg, clip_each)
+    mirr = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    ops.adam_step(pr, gr, mr, vr, n, 1e-2, 0.9, 0.999, 1e-8, 3, mirror=mirr)
+    # fused path: one sum-of-squares pass over the RAW gradients
+    pf, gf, mf, vf = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    mirf = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    ops.segment_sumsq(gf, offs, ss, nseg)
+    ops.adam_step_segments(pf, gf, mf, vf, n, ops.segment_chunks(offs_l, chunk=1000, device=dev), ss, nseg, clip_global, clip_each, 1e-2, 0.9, 0.999, 1e-8, 3, mirror=mirf,
+                           zero_grad=True)
+    torch.cuda.synchronize()
+    assert rel_err(pf, pr) <= 2e-6 and rel_err(mf, mr) <= 2e-6 and rel_err(vf, vr) <= 4e-6
+    assert float((mirf.float() - mirr.float()).abs().max()) <= 2e-2 * float(mirr.float().abs().max())
+    assert float(gf.abs().max()) == 0.0
+
+
 def small_cfg():
     return dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
                 conv_dim=(64, 64, 64), conv_stride=(5, 2, 2), conv_kernel=(10, 3, 2), num_conv_pos_embeddings=8,

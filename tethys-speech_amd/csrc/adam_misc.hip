@@ -254,7 +254,113 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float* __restrict__ p, f
   }
 }
 
+// Adam over the reference's variables with the gradient clipping of V:1243 (tf.clip_by_global_norm before the update)
+// and V:1274 (Keras clipnorm: tf.clip_by_norm per variable) folded in as a per-variable factor of g, from ONE
+// sum-of-squares pass over the raw gradients:
+//   c_g = clip_global / max(sqrt(sum_s sumsq[s]), clip_global)                 (1 when clip_global == 0)
+//   c_s = clip_each   / max(c_g * sqrt(sumsq[s]), clip_each)                   (1 when clip_each == 0)
+//   g'  = g * gscale * c_g * c_s
+// The arena is walked as a table of chunks (lo, hi, variable) of at most a few thousand elements, never crossing a
+// variable boundary (built once per model on the host): workgroups stride over the table, so the launch is as
+// uniform as the flat kernel's.  No clipped copy of the arena is written.
+template <bool ZG>
+__global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                            float* __restrict__ v, const int64_t* __restrict__ chunks,
+                                                            int64_t nchunks,
+                                                            const float* __restrict__ sumsq, int nseg, float clip_global,
+                                                            float clip_each, float b1, float b2, float eps, float step_size,
+                                                            float vcorr_inv_sqrt, int eps_mode, float decay, float gscale,
+                                                            bf16_t* __restrict__ mirror) {
+  __shared__ float red[4];
+  float cg = 1.0f;
+  if (clip_global > 0.f) {
+    float t = 0.f;
+    for (int i = threadIdx.x; i < nseg; i += 256) t += sumsq[i];
+    t = block_sum_256(t, red);
+    cg = clip_global / fmaxf(sqrtf(t), clip_global);
+  }
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  const int64_t a = chunks[3 * ch], b = chunks[3 * ch + 1];
+  const int sgi = (int)chunks[3 * ch + 2];
+  float cs = 1.0f;
+  if (clip_each > 0.f) cs = clip_each / fmaxf(cg * sqrtf(sumsq[sgi]), clip_each);
+  const float scale = gscale * cg * cs;
+  const bool vec = (a & 3) == 0;
+  const int64_t nv = vec ? (b - a) / 4 : 0;
+  auto upd = [&](int64_t e, f32x4 pp, const f32x4 gg, f32x4 mm, f32x4 vv) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = pp[j], y = mm[j], z = vv[j];
+      adam1(x, gg[j], y, z, b1, b2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, scale);
+      pp[j] = x; mm[j] = y; vv[j] = z;
+    }
+    *reinterpret_cast<f32x4*>(p + e) = pp;
+    *reinterpret_cast<f32x4*>(m + e) = mm;
+    *reinterpret_cast<f32x4*>(v + e) = vv;
+    if constexpr (ZG) *reinterpret_cast<f32x4*>(g + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (mirror) {
+      bf16x4 sh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sh[j] = (bf16_t)pp[j];
+      *reinterpret_cast<bf16x4*>(mirror + e) = sh;
+    }
+  };
+  int64_t i = threadIdx.x;
+  for (; i + 256 < nv; i += 512) {  // two 4 x 16-byte load groups in flight per thread
+    const int64_t e0 = a + 4 * i, e1 = e0 + 1024;
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p + e0), g0 = *reinterpret_cast<const f32x4*>(g + e0);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(m + e0), v0 = *reinterpret_cast<const f32x4*>(v + e0);
+    const f32x4 p1 = *reinterpret_cast<const f32x4*>(p + e1), g1 = *reinterpret_cast<const f32x4*>(g + e1);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(m + e1), v1 = *reinterpret_cast<const f32x4*>(v + e1);
+    upd(e0, p0, g0, m0, v0);
+    upd(e1, p1, g1, m1, v1);
+  }
+  for (; i < nv; i += 256) {
+    const int64_t e = a + 4 * i;
+    upd(e, *reinterpret_cast<const f32x4*>(p + e), *reinterpret_cast<const f32x4*>(g + e), *reinterpret_cast<const f32x4*>(m + e),
+        *reinterpret_cast<const f32x4*>(v + e));
+  }
+  for (int64_t e = a + nv * 4 + threadIdx.x; e < b; e += 256) {
+    adam1(p[e], g[e], m[e], v[e], b1, b2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, scale);
+    if constexpr (ZG) g[e] = 0.f;
+    if (mirror) mirror[e] = (bf16_t)p[e];
+  }
+  }
+}
+
 }  // namespace
+
+extern "C" int tmi_adam_step_segments(float* p, float* g, float* m, float* v, const int64_t* chunks, int64_t nchunks,
+                                      const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr, float beta1, float beta2,
+                                      float eps, int32_t step, int32_t eps_mode, float weight_decay, float gscale,
+                                      void* bf16_mirror, int32_t zero_grad, void* stream) {
+  if (!p || !g || !m || !v || !chunks || nchunks <= 0 || nseg <= 0 || step <= 0 || (eps_mode != 0 && eps_mode != 1) ||
+      ((clip_global > 0.f || clip_each > 0.f) && !sumsq) || clip_global < 0.f || clip_each < 0.f || !al16(p) || !al16(g) ||
+      !al16(m) || !al16(v) || (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7))) {
+    tmi_set_error("tmi_adam_step_segments: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  const double c1 = 1.0 - pow((double)beta1, (double)step);
+  const double c2 = 1.0 - pow((double)beta2, (double)step);
+  float step_size, vcorr_inv_sqrt;
+  if (eps_mode == 0) {
+    step_size = (float)((double)lr * sqrt(c2) / c1);
+    vcorr_inv_sqrt = 1.0f;
+  } else {
+    step_size = (float)((double)lr / c1);
+    vcorr_inv_sqrt = (float)(1.0 / sqrt(c2));
+  }
+  const float decay = 1.0f - lr * weight_decay;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)(nchunks < 1024 ? nchunks : 1024));
+  if (zero_grad)
+    hipLaunchKernelGGL(adam_segments_kernel<true>, grid, dim3(256), 0, s, p, g, m, v, chunks, nchunks, sumsq, (int)nseg, clip_global,
+                       clip_each, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale, (bf16_t*)bf16_mirror);
+  else
+    hipLaunchKernelGGL(adam_segments_kernel<false>, grid, dim3(256), 0, s, p, g, m, v, chunks, nchunks, sumsq, (int)nseg, clip_global,
+                       clip_each, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale, (bf16_t*)bf16_mirror);
+  return tmi_check_launch("tmi_adam_step_segments");
+}
 
 extern "C" int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
                                   unsigned char* active, float lr, float beta1, float beta2, float eps, int32_t step,

@@ -287,6 +287,29 @@ def adam_step(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode=0, weight_dec
                                   max_blocks, stream()), "tmi_adam_step")
 
 
+def segment_chunks(seg_off, chunk=8192, device=None):
+    """(lo, hi, variable) pieces of at most ``chunk`` elements that tile the variables of ``seg_off`` (a host list or
+    tensor of nseg + 1 element offsets): the table tmi_adam_step_segments walks."""
+    offs = [int(x) for x in (seg_off.tolist() if hasattr(seg_off, "tolist") else seg_off)]
+    rows = []
+    for s_, (lo, hi) in enumerate(zip(offs[:-1], offs[1:])):
+        a = lo
+        while a < hi:
+            b = min(hi, a + chunk)
+            rows.append((a, b, s_))
+            a = b
+    return torch.tensor(rows, dtype=torch.int64, device=device).reshape(-1, 3)
+
+
+def adam_step_segments(p, g, m, v, n, chunks, sumsq, nseg, clip_global, clip_each, lr, beta1, beta2, eps, step, eps_mode=0,
+                       weight_decay=0.0, gscale=1.0, mirror=None, zero_grad=False):
+    with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * n):
+        check(lib().tmi_adam_step_segments(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), chunks.data_ptr(),
+                                           chunks.shape[0], ptr(sumsq), nseg, clip_global, clip_each, lr, beta1, beta2, eps, step, eps_mode,
+                                           weight_decay, gscale, ptr(mirror), 1 if zero_grad else 0, stream()),
+              "tmi_adam_step_segments")
+
+
 def adam_step_rows(p, g, m, v, nrows, row_len, active, lr, beta1, beta2, eps, step, eps_mode=0, gscale=1.0, mirror=None,
                    zero_grad=False):
     """Adam over an embedding table, idle rows skipped (tmi_adam_step_rows).  Algorithmic bytes as the dense kernel's

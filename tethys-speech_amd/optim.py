@@ -75,6 +75,19 @@ class Adam:
             f = store[key] = (torch.zeros if fresh else torch.ones)(rows, dtype=torch.uint8, device=model.device)
         return f
 
+    def apply_gradients_clipped(self, model, chunks, sumsq, nseg, clip_global=0.0, clip_each=0.0, grad_scale=1.0,
+                                zero_grad=False):
+        """Adam with V:1243's global-norm clip and / or V:1274's per-variable clipnorm folded into the kernel as a factor
+        of g (``sumsq``: per-variable sums of squares of the raw gradients, ops.segment_sumsq; ``chunks``: ops.segment_chunks of
+        the variables' offsets): no clipped copy of the
+        gradient arena is written or re-read."""
+        a = model.arena
+        self.iterations += 1
+        ops.adam_step_segments(a.p, a.g, a.m, a.v, a.numel, chunks, sumsq, nseg, clip_global, clip_each, self.learning_rate,
+                               self.beta_1, self.beta_2, self.epsilon, self.iterations, self.eps_mode, self.weight_decay,
+                               grad_scale, mirror=model.mirror, zero_grad=zero_grad)
+        a.g_clean = bool(zero_grad)
+
     # -- the update bucket by bucket under backward -------------------------------------------------------------
     # Adam is a 4.4 GB/step HBM stream (small-ref) that needs nothing but final gradients: instead of one launch
     # behind backward it runs slice by slice on its own stream as the strategy releases buckets (after the bucket's

@@ -282,16 +282,24 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
     else:  # the reference's empty-batch branch (V:1196-1198, V:1250-1254)
         a.g.zero_()
         loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+    model._prepare_clip()
     ws = model.ws
-    if audio.shape[0] > 0:
-        ops.segment_sumsq(a.g, model.seg_all, ws["clip_all"], 1)
-        ops.segment_clip(a.g, model.seg_all, ws["clip_all"], 1, 1.0)
-    strategy.all_reduce_gradients(a.g)
-    if audio.shape[0] > 0 or strategy.num_replicas_in_sync > 1:
-        model._prepare_clip()
-        ops.segment_sumsq(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var)
-        ops.segment_clip(a.g, model.seg_vars, model.ws["clip_vars"], model.n_var, 1.0)
-    optimizer.apply_gradients(model, None, zero_grad=True)
+    if strategy.num_replicas_in_sync == 1:
+        # one replica: both clips are factors of the same raw gradients, so ONE sum-of-squares pass (per variable; the
+        # global norm is their sum) feeds an Adam launch that applies c_global * c_variable on the fly
+        if audio.shape[0] > 0:
+            ops.segment_sumsq(a.g, model.seg_vars, ws["clip_vars"], model.n_var)
+            optimizer.apply_gradients_clipped(model, model.seg_chunks, ws["clip_vars"], model.n_var, clip_global=1.0,
+                                              clip_each=1.0, zero_grad=True)
+        else:
+            optimizer.apply_gradients(model, None, zero_grad=True)
+    else:
+        if audio.shape[0] > 0:  # V:1243: local, before the exchange (the clipped gradients are what is summed)
+            ops.segment_sumsq(a.g, model.seg_all, ws["clip_all"], 1)
+            ops.segment_clip(a.g, model.seg_all, ws["clip_all"], 1, 1.0)
+        strategy.all_reduce_gradients(a.g)
+        ops.segment_sumsq(a.g, model.seg_vars, ws["clip_vars"], model.n_var)  # V:1274 on the aggregated gradients
+        optimizer.apply_gradients_clipped(model, model.seg_chunks, ws["clip_vars"], model.n_var, clip_each=1.0, zero_grad=True)
     model._pack_pos()
     return strategy.reduce_sum(loss.clone())
 

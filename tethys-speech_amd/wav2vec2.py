@@ -174,6 +174,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # per-variable segments must tile [start, end) without gaps for the offset-array form;
         # alignment padding between tensors belongs to the preceding variable's tail (zeros)
         self.seg_vars = so.to(self.device)
+        self.seg_chunks = ops.segment_chunks(so, device=self.device)  # the table Adam-with-clipping walks
         self.seg_all = torch.tensor([0, self.arena.numel], dtype=torch.int64, device=self.device)
         self.refresh_shadows()
         # weight / bias gradients on a second stream beside the dgrad chain (blocks.KernelBlocks): 6.03 -> 5.9 ms
