@@ -32,6 +32,7 @@ def _mul24(a, b):
 
 def pair_hash(pid, key):
     a = (_u32(pid) ^ _u32(key)) & M32
+    a ^= a >> np.uint64(17)  # fold bits 17..31 into the 24 the multiplier sees (counters >= 2^24, full-width keys)
     h = _mul24(a, 0x9E3779)
     h ^= h >> np.uint64(15)
     return (_mul24(h, 0x85EBCB) + (a >> np.uint64(8))) & M32

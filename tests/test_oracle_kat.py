@@ -277,15 +277,15 @@ def test_dropout_generator_known_answers_and_statistics():
     Bernoulli draws (rate, adjacent / cross-row / cross-stream / cross-step correlation)."""
     from oracle import dropout as D
     assert [int(D.pair_hash(i, k)) for i, k in ((0, 0), (1, 0), (12345, 0xDEADBEEF), (0xFFFFFFFF, 0x12345678))] == \
-        [0, 3944701879, 4262915128, 3372026424]
+        [0, 3944701879, 1023874381, 3419432724]
     assert (int(D.mix32(1)), int(D.mix32(0xDEADBEEF)), int(D.stream_key(0x0123456789ABCDEF, 7))) == \
         (1753845952, 3861431939, 1429204582)
     assert D.drop_thr(0.1) == 6554 and D.drop_thr(0.25) == 16384
     assert abs(D.keep_scale(0.1) - 65536.0 / (65536 - 6554)) < 1e-6
-    assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 0, 1, 1, 0, 1, 1, 1], [1, 1, 1, 0, 1, 1, 1, 0],
-                                                              [1, 1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 0, 1]]
+    assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 1, 1, 1, 0, 1, 1, 1], [1, 0, 1, 1, 1, 1, 1, 1],
+                                                              [1, 1, 1, 0, 1, 1, 1, 1], [1, 1, 1, 1, 0, 1, 0, 1]]
     assert D.keep_attention(42, 1, 2, 3, 6, 0.5).astype(int).tolist() == \
-        [[[[0, 0, 0, 0, 0, 0], [1, 0, 1, 1, 1, 0], [1, 0, 1, 0, 1, 0]], [[0, 0, 1, 0, 1, 0], [1, 0, 0, 1, 0, 1], [1, 1, 1, 1, 1, 0]]]]
+        [[[[1, 0, 1, 1, 0, 1], [0, 1, 1, 0, 1, 1], [0, 1, 1, 1, 0, 0]], [[0, 1, 0, 1, 0, 0], [0, 0, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1]]]]
     assert D.site_seed(0xC0FFEE, 3, 204) == 17806544269414322833
     assert D.site_id("decoder.layers.3.encoder_attn") == 403 and D.w2v_site_id("encoder.layers.11.attention_output") == 211
     m = D.keep_flat(7, 600, 768, 0.1)
@@ -300,3 +300,22 @@ def test_dropout_generator_known_answers_and_statistics():
     s1 = D.keep_flat(D.site_seed(5, 1, 100), 300, 256, 0.1).ravel().astype(float)
     s2 = D.keep_flat(D.site_seed(5, 0, 101), 300, 256, 0.1).ravel().astype(float)
     assert abs(np.corrcoef(s0, s1)[0, 1]) < 5 / np.sqrt(s0.size) and abs(np.corrcoef(s0, s2)[0, 1]) < 5 / np.sqrt(s0.size)
+
+
+def test_dropout_hash_uses_every_counter_and_key_bit():
+    """ADVICE r1 (tmi_common.h:89): the pair hash multiplies 24-bit quantities; without folding the high bits in first,
+    counter pairs 2^24 apart (elements 2^25 apart: Whisper-large at batch >= 18) and stream keys equal in their low 24
+    bits draw (almost) the same masks.  With the fold the masks are independent: agreement ~ 0.9^2 + 0.1^2 = 0.82."""
+    from oracle import dropout as DO
+    thr = DO.drop_thr(0.1)
+    idx = np.arange(1 << 18, dtype=np.uint64)
+    key = DO.stream_key(0x1234567890ABCDEF, 7)
+    a = DO.keep_counter(key, idx, thr)
+    b = DO.keep_counter(key, idx + np.uint64(1 << 25), thr)
+    assert abs(a.mean() - 0.9) < 3e-3 and abs(b.mean() - 0.9) < 3e-3
+    assert abs((a == b).mean() - 0.82) < 5e-3
+    key2 = (int(key) ^ 0xA5000000) & 0xFFFFFFFF  # differs in the top byte only
+    c = DO.keep_counter(np.uint64(key2), idx, thr)
+    assert abs((a == c).mean() - 0.82) < 5e-3
+    # low and high 16-bit draws of one pair are independent too
+    assert abs((a[0::2] == a[1::2]).mean() - 0.82) < 5e-3

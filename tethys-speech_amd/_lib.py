@@ -107,7 +107,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 _lib = None
 
 

@@ -78,7 +78,7 @@ __host__ __device__ __forceinline__ uint32_t tmi_mix32(uint32_t x) {  // "lowbia
   return x;
 }
 // pair hash: 32 bits for the counter pair `pid` of a stream with key `key`.  Built on 24-bit multiplies
-// (v_mul_u32_u24 / v_mad_u32_u24 are full-rate VALU instructions, the 32-bit v_mul_lo_u32 is quarter rate): five
+// (v_mul_u32_u24 / v_mad_u32_u24 are full-rate VALU instructions, the 32-bit v_mul_lo_u32 is quarter rate): seven
 // instructions per two elements inside the attention kernels, which are VALU-bound.
 __host__ __device__ __forceinline__ uint32_t tmi_mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -88,7 +88,10 @@ __host__ __device__ __forceinline__ uint32_t tmi_mul24(uint32_t a, uint32_t b) {
 #endif
 }
 __host__ __device__ __forceinline__ uint32_t tmi_pair_hash(uint32_t pid, uint32_t key) {
-  const uint32_t a = pid ^ key;
+  uint32_t a = pid ^ key;
+  a ^= a >> 17;  // the 24-bit multiplier sees only bits 0..23: fold 17..31 in first, so that counter pairs 2^24 apart
+                 // (tensors beyond 2^25 elements: Whisper-large at batch >= 18) and keys that differ only in their
+                 // top byte draw different masks
   uint32_t h = tmi_mul24(a, 0x9E3779u);
   h ^= h >> 15;
   return tmi_mul24(h, 0x85EBCBu) + (a >> 8);

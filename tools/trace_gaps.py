@@ -4,7 +4,10 @@ import csv, glob, sys
 d = sys.argv[1]
 tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(tr))))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+# a step ends with its LAST optimizer launch (the update may be several launches: dense ranges, the row-sparse
+# embedding table, or the segmented Adam-with-clipping): consecutive Adam launches with nothing between them are one
+adam_all = [i for i, r in enumerate(rows) if "adam_" in r[2] and "kernel" in r[2]]
+adam = [i for k, i in enumerate(adam_all) if k + 1 == len(adam_all) or adam_all[k + 1] != i + 1]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lo, hi = adam[-nsteps - 1] + 1, adam[-1] + 1
 seg = rows[lo:hi]
