@@ -35,6 +35,7 @@
 // 32 cycles, v_exp_f32 costs 8 issue cycles and every other vector op 4.
 #include "tmi_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -186,6 +187,7 @@ __device__ __forceinline__ void store_owner(const f32x16 (&y)[2], bf16_t* base, 
   }
 }
 
+
 #define ZERO2(y)                          \
   _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) y[i_][e_] = 0.f
 
@@ -202,7 +204,9 @@ struct AttnP {
   uint32_t seed_lo, seed_hi;
 };
 
-template <bool DROP, int OCC>
+// ABL (diagnostics, TMI_ATTN_ABL): 1 = no softmax arithmetic (p = s), 2 = no second product, 3 = no staging after the
+// prologue (every tile re-reads tile 0's images), 4 = no first product
+template <bool DROP, int OCC, int ABL = 0>
 __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
@@ -243,17 +247,26 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
     constexpr bool edge = decltype(edge_tag)::value;
     const char* Kimg = smem + cur * 2 * IMG;
     const char* Vimg = Kimg + IMG;
-    if (tile + 1 < ntiles) {
+    if (ABL != 3 && tile + 1 < ntiles) {
       char* nx = smem + (cur ^ 1) * 2 * IMG;
       stage_tile(nx, Ks, (tile + 1) * TROWS, wave, lane);
       stage_tile(nx + IMG, Vs, (tile + 1) * TROWS, wave, lane);
     }
     f32x16 s[2];
+    if constexpr (ABL == 4) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[0][e] = (float)(tile + e) * 0.01f; s[1][e] = (float)(tile - e) * 0.01f; }
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+    } else {
     s[0] = first_product(Kimg, 0, qf, c, h);   // s[key][q], keys 0..31 of the tile
     s[1] = first_product(Kimg, 32, qf, c, h);  // keys 32..63
+    }
     const int key0 = tile * TROWS;
     float rs = 0.f;
-    if constexpr (!edge) {
+    if constexpr (ABL == 1) {
+      asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+      rs = 1.f;
+    } else if constexpr (!edge) {
       // branch-free tile: maximum over the raw products (c2 > 0), lazy rescale
       float mx = max3(s[0][0], s[0][1], s[0][2]);
 #pragma unroll
@@ -330,11 +343,15 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
             if ((hh >> 16) < drop_thr) s[rbk][4 * g + 2 * j + 1] = 0.f;
           }
     }
+    if constexpr (ABL == 2) {
+      asm volatile("" :: "v"(s[0]), "v"(s[1]));
+    } else {
     second_product(Vimg, 0, s[0], o, lane);
     second_product(Vimg, 32, s[1], o, lane);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    if (ABL != 3) cur ^= 1;
   };
   const int nfast = causal ? 0 : Tk / TROWS;  // full, unmasked tiles first
   int tile = 0;
@@ -661,10 +678,17 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   P.c2 = P.sscale * LOG2E;
   set_dropout(P);
   dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  if (P.drop_thr)
-    hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, reinterpret_cast<hipStream_t>(stream), P);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (P.drop_thr) {
+    hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
+  } else {
+    static const int abl = [] { const char* e = getenv("TMI_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 1>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 2>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (abl == 3) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 3>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 4>), grid, dim3(256), 4 * IMG, hs, P);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, hs, P);
+  }
   return tmi_check_launch("tmi_attn_fwd");
 }
 
