@@ -6,6 +6,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))  # tests/_margins.py
 
 
 def pytest_configure(config):
@@ -18,3 +19,18 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured-vs-bound table of the tolerance checks that go through tests/_margins.within."""
+    try:
+        from _margins import MARGINS
+    except Exception:
+        return
+    if not MARGINS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "margins.json"), "w") as f:
+        json.dump(MARGINS, f, indent=1, sort_keys=True)

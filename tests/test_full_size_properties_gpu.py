@@ -96,7 +96,9 @@ def test_whisper_large_one_layer_each_matches_oracle(dev):
         model.arena.load_ref(params)
         model.refresh_shadows()
         loss = float(model.forward_backward(torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev)).item())
-        assert abs(loss - float(loss_ref)) <= ltol, (precision, loss, float(loss_ref))
+        from _margins import within
+        within(f"whisper-large 1+1 layers {precision} |dloss|", abs(loss - float(loss_ref)), ltol)
+        worst = 0.0
         got = model.arena.ref_views(model.arena.g)
         bad = {}
         for k, gr in grads_ref.items():
@@ -117,6 +119,9 @@ def test_whisper_large_one_layer_each_matches_oracle(dev):
                 err = float((gg - gr).norm() / max(float(gr.norm()), 1e-3))
                 if err > 6e-2:
                     bad[k] = err
+            worst = max(worst, err)
+        within(f"whisper-large 1+1 layers {precision} worst gradient (fp32: max-norm, bf16: rel L2)", worst,
+               2e-4 if precision == "fp32" else 6e-2, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
         assert not bad, (precision, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
         del model
         torch.cuda.empty_cache()

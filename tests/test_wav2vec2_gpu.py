@@ -267,9 +267,14 @@ def test_wav2vec2_step_gradients_match_oracle(dev, precision):
         loss_ref, grads_ref, out = V.loss_and_grads(params, torch.from_numpy(pool), torch.from_numpy(neg), ocfg,
                                                     num_replicas=2, force_idx=kidx)
     lv, lr = float(loss.item()), float(loss_ref)
-    assert abs(lv - lr) <= (1e-4 if precision == "fp32" else 1e-2 * abs(lr)), (lv, lr)
+    from _margins import within
+    if precision == "fp32":
+        within("wav2vec2 step fp32 |dloss|", abs(lv - lr), 1e-4, (lv, lr))
+    else:
+        within("wav2vec2 step bf16 |dloss| / |loss|", abs(lv - lr) / abs(lr), 1e-2, (lv, lr))
     got = model.arena.ref_views(model.arena.g)
     bad = {}
+    worst = 0.0
     # tensors whose true gradient is exactly zero (k_proj.bias: softmax shift invariance;
     # project_q beta: a common shift of every logit of a row) are measured against a floor tied
     # to the step's gradient scale
@@ -285,7 +290,9 @@ def test_wav2vec2_step_gradients_match_oracle(dev, precision):
             err = float((gg - gr).norm() / max(float(gr.norm()), 1e-2 * nmax))
             if err > 6e-2:
                 bad[k] = err
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+        worst = max(worst, err)
+    within(f"wav2vec2 step {precision} worst gradient (fp32: max-norm, bf16: rel L2)", worst, 1e-4 if precision == "fp32" else 6e-2,
+           sorted(bad.items(), key=lambda kv: -kv[1])[:8])
     assert float(got["quantizer.projection.kernel"].abs().max()) == 0.0  # no gradient path (V:631-638)
 
 
@@ -388,9 +395,13 @@ def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
         # then differs): hold the first two steps to 3 %, the rest to a loose band (the order of the fp32
         # atomic adds inside the weight-gradient / GroupNorm / LayerNorm kernels varies from run to run and is
         # enough to move step 3 by 3-4 % and step 4 by 15 %)
-        assert max(rel[:2]) <= 0.03 and max(rel) <= 0.35 and all(np.isfinite(got)), (rel, got, gold["losses"])
+        from _margins import within
+        within("wav2vec2-base B=2 golden bf16 rel, steps 0-1", max(rel[:2]), 0.03, (rel, got))
+        within("wav2vec2-base B=2 golden bf16 rel, steps 2-4 (chaotic after a code flip)", max(rel), 0.35, (rel, got))
+        assert all(np.isfinite(got))
     else:
-        assert max(rel) <= tol, (rel, got, gold["losses"])
+        from _margins import within
+        within("wav2vec2-base B=2 5-step golden fp32 max rel", max(rel), tol, (rel, got, gold["losses"]))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -473,7 +484,8 @@ def test_whisper_single_base_golden_fp32(dev):
                                        torch.from_numpy(neg).to(dev), opt)
         got.append(float(loss.item()))
     rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
-    assert max(rel) <= 2e-3, (rel, got, gold["losses"])
+    from _margins import within
+    within("whisper_single (W2V2-base, 5 s) B=2 10-step golden fp32 max rel", max(rel), 2e-3, (rel, got, gold["losses"]))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -59,7 +59,8 @@ def test_step_gradients_match_oracle(dev, precision, T_in):
     loss = model.forward_backward(torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev))
     torch.cuda.synchronize()
     lv = float(loss.item())
-    assert abs(lv - float(loss_ref)) <= (1e-5 if precision == "fp32" else 2e-2), (lv, float(loss_ref))
+    from _margins import within
+    within(f"whisper step {precision} |dloss|", abs(lv - float(loss_ref)), 1e-5 if precision == "fp32" else 2e-2)
     got = model.arena.ref_views(model.arena.g)
     worst = {}
     for k, gr in grads_ref.items():
@@ -71,8 +72,8 @@ def test_step_gradients_match_oracle(dev, precision, T_in):
         else:
             err = float((gg - gr).norm() / max(float(gr.norm()), 1e-2))
         worst[k] = err
-    bad = {k: v for k, v in worst.items() if v > (1e-4 if precision == "fp32" else 6e-2)}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+    within(f"whisper step {precision} worst gradient (fp32: max-norm, bf16: rel L2)", max(worst.values()),
+           1e-4 if precision == "fp32" else 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4])
 
 
 def test_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
@@ -98,14 +99,12 @@ def test_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
             torch.cuda.synchronize()
             lv = float(loss.item())
             losses.append((lv, float(loss_ref)))
-            assert abs(lv - float(loss_ref)) <= 2e-2, losses
+            from _margins import within
+            within("whisper step bf16 + dropout |dloss|", abs(lv - float(loss_ref)), 2e-2, losses)
             got = model.arena.ref_views(model.arena.g)
-            bad = {}
-            for k, gr in grads_ref.items():
-                err = float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2))
-                if err > 6e-2:
-                    bad[k] = err
-            assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
+            errs = {k: float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2)) for k, gr in grads_ref.items()}
+            within("whisper step bf16 + dropout worst gradient rel L2", max(errs.values()), 6e-2,
+                   sorted(errs.items(), key=lambda kv: -kv[1])[:4])
     finally:
         O.DROPOUT_PROVIDER = None
     # the two steps drew different masks (same batch, same weights: the losses differ) and dropout is really on
@@ -188,7 +187,8 @@ def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
                                                            torch.from_numpy(np.ascontiguousarray(l)).to(dev)), opt)
         got.append(float(loss.item()))
     err = max(abs(a - b) for a, b in zip(got, gold["losses"]))
-    assert err <= tol, (err, got, gold["losses"])
+    from _margins import within
+    within(f"whisper-tiny B=2 10-step golden {precision} max |dloss|", err, tol, (got, gold["losses"]))
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
@@ -225,4 +225,5 @@ def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     assert sizes == [8, 8, 8, 8, 8, 8, 2, 8, 8, 8]
     err = [abs(a - b) for a, b in zip(got, gold["losses"])]
     print(f"small-ref B=8 {precision}: max |dloss| = {max(err):.2e} (bound {tol:g}); per step {['%.1e' % e for e in err]}")
-    assert max(err) <= tol, (err, got, gold["losses"])
+    from _margins import within
+    within(f"whisper small-ref B=8 10-step golden {precision} max |dloss|", max(err), tol, (err, got, gold["losses"]))
