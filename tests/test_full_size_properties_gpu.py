@@ -75,8 +75,8 @@ def test_whisper_large_one_layer_each_matches_oracle(dev):
     """BASELINE configs[4] dimensions (Whisper "large", W:880-886: d_model 1280, 20 heads, d_ff 5120) with ONE encoder
     and ONE decoder layer, full-length clips (T = 1500, S = 100), full vocabulary, B = 2: loss and every gradient of
     the step against the fp64 oracle.  d = 1280 / H = 20 take other tile-selection branches than small-ref
-    (profiles/r01_gemm_rule_probe.txt).  fp32 path: loss 1e-4, gradients 2e-4 of max|ref| per tensor; bf16 path:
-    loss 2e-2, gradients 6e-2 relative L2."""
+    (profiles/r01_gemm_rule_probe.txt).  fp32 path: loss 1e-5, gradients 2e-5 of max|ref| per tensor; bf16 path:
+    loss 1e-3, gradients 2e-2 relative L2 (about 3-6x what is measured: profiles/r02_test_margins.json)."""
     import numpy as np
     import tethys_speech_amd  # noqa: F401
     from tethys_speech_amd import whisper
@@ -91,7 +91,7 @@ def test_whisper_large_one_layer_each_matches_oracle(dev):
             v.copy_(torch.randn(v.shape, generator=g, dtype=torch.float64) * 0.02)
     feats, labels = O.create_dummy_pool(seed=7, num_samples=2)
     loss_ref, grads_ref = O.loss_and_grads(params, torch.from_numpy(feats), torch.from_numpy(labels), ocfg)
-    for precision, ltol in (("fp32", 1e-4), ("bf16", 2e-2)):
+    for precision, ltol in (("fp32", 1e-5), ("bf16", 1e-3)):  # measured 1.7e-7 / 1.6e-4
         model = whisper.create_whisper_model("large", device=dev, precision=precision, encoder_layers=1, decoder_layers=1)
         model.arena.load_ref(params)
         model.refresh_shadows()
@@ -113,15 +113,15 @@ def test_whisper_large_one_layer_each_matches_oracle(dev):
                 continue
             if precision == "fp32":
                 err = float((gg - gr).abs().max() / max(float(gr.abs().max()), 1e-12))
-                if err > 2e-4:
+                if err > 2e-5:
                     bad[k] = err
             else:
                 err = float((gg - gr).norm() / max(float(gr.norm()), 1e-3))
-                if err > 6e-2:
+                if err > 2e-2:
                     bad[k] = err
             worst = max(worst, err)
         within(f"whisper-large 1+1 layers {precision} worst gradient (fp32: max-norm, bf16: rel L2)", worst,
-               2e-4 if precision == "fp32" else 6e-2, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+               2e-5 if precision == "fp32" else 2e-2, sorted(bad.items(), key=lambda kv: -kv[1])[:8])  # measured 3.3e-6 / 7.3e-3
         assert not bad, (precision, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
         del model
         torch.cuda.empty_cache()

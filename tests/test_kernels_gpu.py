@@ -312,7 +312,7 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     ref_o = outr.permute(0, 2, 1, 3).reshape(B, Tq, D)
     from _margins import within
     tag = f"attn[{'drop' if drop > 0 else 'nodrop'},mask{mask}]"
-    within(tag + " fwd o", rel_err(o, ref_o), 2e-2)
+    within(tag + " fwd o", rel_err(o, ref_o), 1e-2)        # measured <= 4.4e-3 (profiles/r02_test_margins.json)
     do = rnd((B, Tq, D), bf, dev, 53)
     outr.backward(heads(do, Tq))
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -325,9 +325,9 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     def merge(t, T):
         return t.permute(0, 2, 1, 3).reshape(B, T, D)
 
-    within(tag + " bwd dv", rel_err(dv, merge(vr.grad, Tk)), 3e-2)
-    within(tag + " bwd dk", rel_err(dk, merge(kr.grad, Tk)), 3e-2)
-    within(tag + " bwd dq", rel_err(dq, 0.5 * merge(qr.grad, Tq)), 3e-2)
+    within(tag + " bwd dv", rel_err(dv, merge(vr.grad, Tk)), 1.5e-2)   # measured <= 4.7e-3
+    within(tag + " bwd dk", rel_err(dk, merge(kr.grad, Tk)), 1.5e-2)   # measured <= 6.2e-3
+    within(tag + " bwd dq", rel_err(dq, 0.5 * merge(qr.grad, Tq)), 1.5e-2)   # measured <= 5.9e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -269,9 +269,9 @@ def test_wav2vec2_step_gradients_match_oracle(dev, precision):
     lv, lr = float(loss.item()), float(loss_ref)
     from _margins import within
     if precision == "fp32":
-        within("wav2vec2 step fp32 |dloss|", abs(lv - lr), 1e-4, (lv, lr))
+        within("wav2vec2 step fp32 |dloss|", abs(lv - lr), 1e-5, (lv, lr))  # measured 2.9e-7 (loss O(70))
     else:
-        within("wav2vec2 step bf16 |dloss| / |loss|", abs(lv - lr) / abs(lr), 1e-2, (lv, lr))
+        within("wav2vec2 step bf16 |dloss| / |loss|", abs(lv - lr) / abs(lr), 5e-3, (lv, lr))  # measured 2.0e-3
     got = model.arena.ref_views(model.arena.g)
     bad = {}
     worst = 0.0
@@ -284,14 +284,14 @@ def test_wav2vec2_step_gradients_match_oracle(dev, precision):
         gg = got[k].double().cpu()
         if precision == "fp32":
             err = float((gg - gr).abs().max() / max(float(gr.abs().max()), 1e-3 * gmax))
-            if err > 1e-4:
+            if err > 5e-5:
                 bad[k] = err
         else:
             err = float((gg - gr).norm() / max(float(gr.norm()), 1e-2 * nmax))
             if err > 6e-2:
                 bad[k] = err
         worst = max(worst, err)
-    within(f"wav2vec2 step {precision} worst gradient (fp32: max-norm, bf16: rel L2)", worst, 1e-4 if precision == "fp32" else 6e-2,
+    within(f"wav2vec2 step {precision} worst gradient (fp32: max-norm, bf16: rel L2)", worst, 5e-5 if precision == "fp32" else 6e-2,  # measured 2.0e-5 / 4.6e-2
            sorted(bad.items(), key=lambda kv: -kv[1])[:8])
     assert float(got["quantizer.projection.kernel"].abs().max()) == 0.0  # no gradient path (V:631-638)
 
@@ -358,7 +358,7 @@ def test_wav2vec2_five_step_loss_curve_fp32(dev):
     assert max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, ref_losses)) <= 2e-4, (got, ref_losses)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 0.15)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 0.15)])  # fp32 measured 2.5e-6 relative
 def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
     """BASELINE config #4 model (Wav2Vec2-base, 2 s clips), B=2, 5 steps of the full step
     (clip, Adam 3e-5), against the committed fp64-oracle curve (tests/golden/make_golden.py).
@@ -396,8 +396,8 @@ def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
         # atomic adds inside the weight-gradient / GroupNorm / LayerNorm kernels varies from run to run and is
         # enough to move step 3 by 3-4 % and step 4 by 15 %)
         from _margins import within
-        within("wav2vec2-base B=2 golden bf16 rel, steps 0-1", max(rel[:2]), 0.03, (rel, got))
-        within("wav2vec2-base B=2 golden bf16 rel, steps 2-4 (chaotic after a code flip)", max(rel), 0.35, (rel, got))
+        within("wav2vec2-base B=2 golden bf16 rel, steps 0-1", max(rel[:2]), 0.01, (rel, got))  # measured 4.3e-3
+        within("wav2vec2-base B=2 golden bf16 rel, steps 2-4 (chaotic after a code flip)", max(rel), 0.25, (rel, got))  # measured 0.06, varies run to run
         assert all(np.isfinite(got))
     else:
         from _margins import within
@@ -485,7 +485,7 @@ def test_whisper_single_base_golden_fp32(dev):
         got.append(float(loss.item()))
     rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
     from _margins import within
-    within("whisper_single (W2V2-base, 5 s) B=2 10-step golden fp32 max rel", max(rel), 2e-3, (rel, got, gold["losses"]))
+    within("whisper_single (W2V2-base, 5 s) B=2 10-step golden fp32 max rel", max(rel), 5e-5, (rel, got, gold["losses"]))  # measured 1.0e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

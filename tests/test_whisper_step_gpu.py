@@ -60,7 +60,7 @@ def test_step_gradients_match_oracle(dev, precision, T_in):
     torch.cuda.synchronize()
     lv = float(loss.item())
     from _margins import within
-    within(f"whisper step {precision} |dloss|", abs(lv - float(loss_ref)), 1e-5 if precision == "fp32" else 2e-2)
+    within(f"whisper step {precision} |dloss|", abs(lv - float(loss_ref)), 1e-6 if precision == "fp32" else 2e-3)  # measured 3e-8 / 8e-4
     got = model.arena.ref_views(model.arena.g)
     worst = {}
     for k, gr in grads_ref.items():
@@ -73,7 +73,7 @@ def test_step_gradients_match_oracle(dev, precision, T_in):
             err = float((gg - gr).norm() / max(float(gr.norm()), 1e-2))
         worst[k] = err
     within(f"whisper step {precision} worst gradient (fp32: max-norm, bf16: rel L2)", max(worst.values()),
-           1e-4 if precision == "fp32" else 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+           5e-5 if precision == "fp32" else 6e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:4])  # measured 2.2e-5 / 4.1e-2
 
 
 def test_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
@@ -100,7 +100,7 @@ def test_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
             lv = float(loss.item())
             losses.append((lv, float(loss_ref)))
             from _margins import within
-            within("whisper step bf16 + dropout |dloss|", abs(lv - float(loss_ref)), 2e-2, losses)
+            within("whisper step bf16 + dropout |dloss|", abs(lv - float(loss_ref)), 2e-3, losses)  # measured 6e-4
             got = model.arena.ref_views(model.arena.g)
             errs = {k: float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2)) for k, gr in grads_ref.items()}
             within("whisper step bf16 + dropout worst gradient rel L2", max(errs.values()), 6e-2,
@@ -161,7 +161,7 @@ def test_ragged_final_batches_bf16(dev):
     assert max(abs(a - b) for a, b in zip(got, ref_losses)) <= 2e-2, (got, ref_losses)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-3)])  # measured 6.5e-7 / 3.9e-4
 def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
     """BASELINE config #1(b): Whisper-tiny (384/6h/1536/4+4), B=2, 10 steps, 30 s clips,
     Adam 1e-4, against the committed fp64-oracle loss curve (tests/golden/make_golden.py)."""
@@ -191,7 +191,7 @@ def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
     within(f"whisper-tiny B=2 10-step golden {precision} max |dloss|", err, tol, (got, gold["losses"]))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2e-3)])  # measured 1.2e-6 / 8.4e-4
 def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     """BASELINE.json's headline model at its headline batch (configs[1]): Whisper small-ref (768/12h/3072/4+4,
     W:13-18), per-GPU batch 8, 30 s clips, Adam 1e-4 (W:901), dropout 0, the bench.py pool (seed 1234), 10 steps
@@ -227,3 +227,5 @@ def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     print(f"small-ref B=8 {precision}: max |dloss| = {max(err):.2e} (bound {tol:g}); per step {['%.1e' % e for e in err]}")
     from _margins import within
     within(f"whisper small-ref B=8 10-step golden {precision} max |dloss|", max(err), tol, (err, got, gold["losses"]))
+    if precision == "fp32":  # the north star's 1e-3 is the contract; what the fp32 path actually holds is ~1e-6
+        assert max(err) <= 1e-5, err
