@@ -86,7 +86,7 @@ typedef struct tmi_gemm_desc {
   int32_t in_dtype, out_dtype;
   void* workspace; int64_t workspace_bytes;
   /* Dropout on the epilogue value, before the residual add (W:205: x + Dropout(fc2(..)); V:396, V:431):
-   * C = resid + (keep ? v / (1 - p) : 0) with the generator of tmi_dropout over the [M, N] output (counter m*N + n).
+   * C = resid + (keep ? v / (1 - p) : 0) with the generator of tmi_dropout over the [M, N] output (row m, column n; N <= 2^17).
    * dropout_p == 0 is off.  nbatch must be 1. */
   float dropout_p; uint64_t dropout_seed;
 } tmi_gemm_desc;
@@ -106,6 +106,16 @@ int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
                       int64_t C, int32_t accumulate_dx, int32_t dtype, void* stream);
 
+/* tmi_layernorm_bwd that also emits what the Dense layer BELOW this LayerNorm's residual stream needs from dx (the
+ * gradient this kernel writes is that layer's dy): colsum[c] += sum over rows of dy' (its bias gradient), where
+ * dy' = dx, or - when that layer's output went through Dropout (W:205, V:396, V:431) - dy' = mask * dx / (1 - p), which is
+ * also written to `masked` [rows][C] (the generator of tmi_dropout over [rows, C] with `dropout_seed`).  masked == NULL or
+ * dropout_p == 0: no mask, column sums of dx.  Replaces a tmi_dropout and a tmi_colsum pass over dx. */
+int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
+                           const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
+                           int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
+                           float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream);
+
 /* out[n] += sum over rows of dY[rows, N] (row stride ld): the bias gradient of a Dense /
  * Conv1D layer.  Accumulates with fp32 atomics (one per column per workgroup); the caller
  * zeroes `out`. */
@@ -117,10 +127,11 @@ int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N,
 int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream);
 /* The same over nbatch spans of n elements whose starts are dy_sb / u_sb / dx_sb elements apart (one
  * launch for the per-sample spans of a padded buffer). */
-/* Dropout (tf.keras.layers.Dropout in training, W:205 / W:342 / W:411) over a [rows, cols] tensor, cols even:
- *   out[r,c] = (resid ? resid[r,c] : 0) + (keep(seed, r*cols + c) ? in[r,c] * 65536/(65536-thr) : 0),
- * thr = round(p * 65536): element e of the counter pair e>>1 is dropped when its 16-bit draw (low / high half of one
- * 32-bit hash of (seed, e>>1)) is below thr.  Nothing is stored: the backward applies the same call (same seed) to the
+/* Dropout (tf.keras.layers.Dropout in training, W:205 / W:342 / W:411) over a [rows, cols] tensor, cols even and
+ * <= 2^17:
+ *   out[r,c] = (resid ? resid[r,c] : 0) + (keep(seed, r, c) ? in[r,c] * 65536/(65536-thr) : 0),
+ * thr = round(p * 65536): element (r, c) is dropped when its 16-bit draw (low / high half, for even / odd c, of one
+ * 32-bit hash of (row key of (seed, r), c>>1)) is below thr.  Nothing is stored: the backward applies the same call (same seed) to the
  * incoming gradient.  TF's RNG stream cannot be reproduced, so the mask differs from the reference's; the oracle
  * restates this generator (oracle/dropout.py).  out may alias in. */
 int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,

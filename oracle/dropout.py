@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE (checker only): numpy restatement of the counter-based dropout generator of
-tethys-speech_amd/csrc/tmi_common.h (tmi_mix32 / tmi_pair_hash / tmi_stream_key / tmi_keep).
+tethys-speech_amd/csrc/tmi_common.h (tmi_mix32 / tmi_row_key / tmi_pair_hash / tmi_stream_key / tmi_keep).
 
 The reference applies tf.keras.layers.Dropout in training (speech_jobs/whisper_dist.py:160, 205, 342, 411);
 TensorFlow's RNG stream cannot be reproduced, so the masks below are this build's own and parity with
@@ -30,12 +30,20 @@ def _mul24(a, b):
     return ((_u32(a) & M24) * (_u32(b) & M24)) & M32
 
 
-def pair_hash(pid, key):
-    a = (_u32(pid) ^ _u32(key)) & M32
-    a ^= a >> np.uint64(17)  # fold bits 17..31 into the 24 the multiplier sees (counters >= 2^24, full-width keys)
-    h = _mul24(a, 0x9E3779)
-    h ^= h >> np.uint64(15)
-    return (_mul24(h, 0x85EBCB) + (a >> np.uint64(8))) & M32
+def row_key(key, row):
+    """tmi_row_key: two full avalanches per mask row (seed, stream and row reach every bit of both words)."""
+    key, row = _u32(key), _u32(row)
+    ra = mix32(key ^ ((row * np.uint64(0x9E3779B1)) & M32))
+    rb = mix32(((key + np.uint64(0x632BE5AB)) & M32) ^ ((row * np.uint64(0x85EBCA6B)) & M32))
+    return ra, rb
+
+
+def pair_hash(rk, cp):
+    """tmi_pair_hash: 32 bits for column pair ``cp`` (= column >> 1) of the row with key ``rk`` = (ra, rb)."""
+    ra, rb = rk
+    h = _mul24(_u32(ra) ^ _u32(cp), 0x9E3779)
+    h = h ^ (h >> np.uint64(15)) ^ _u32(rb)
+    return _mul24(h, 0x85EBCB)
 
 
 def stream_key(seed, stream_id):
@@ -53,33 +61,27 @@ def keep_scale(p):
     return float(np.float32(65536.0) / np.float32(65536 - thr))
 
 
-def keep_counter(key, idx, thr):
-    """keep decision of flat counters ``idx`` (uint64 array) in the stream with key ``key``."""
-    idx = np.asarray(idx, dtype=np.uint64)
-    h = pair_hash((idx >> np.uint64(1)) & M32, key)
-    r = np.where(idx & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xFFFF))
-    return r >= np.uint64(thr)
+def keep_rows(key, rows, cols, thr):
+    """tmi_keep over a [rows, cols] grid of one stream: bool array."""
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    c = np.arange(cols, dtype=np.uint64)[None, :]
+    h = pair_hash(row_key(key, r), c >> np.uint64(1))
+    d = np.where(c & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return d >= np.uint64(thr)
 
 
 def keep_flat(seed, rows, cols, p):
-    """[rows, cols] bool mask of tmi_dropout (cols even): counter = r * cols + c, stream 0."""
-    idx = np.arange(rows * cols, dtype=np.uint64).reshape(rows, cols)
-    return keep_counter(stream_key(seed, 0), idx, drop_thr(p))
+    """[rows, cols] bool mask of tmi_dropout / the GEMM-epilogue and LayerNorm-backward dropout terms: stream 0."""
+    return keep_rows(stream_key(seed, 0), rows, cols, drop_thr(p))
 
 
 def keep_attention(seed, B, H, Tq, Tk, p):
-    """[B, H, Tq, Tk] bool mask of the attention kernels: stream b*H + head, counter q * 2*ceil(Tk/2) + k."""
-    kp = (Tk + 1) // 2
-    q = np.arange(Tq, dtype=np.uint64)[:, None]
-    k = np.arange(Tk, dtype=np.uint64)[None, :]
-    pid = (q * np.uint64(kp) + (k >> np.uint64(1))) & M32
+    """[B, H, Tq, Tk] bool mask of the attention kernels: stream b*H + head, row = query, column = key."""
     out = np.empty((B, H, Tq, Tk), dtype=bool)
-    thr = np.uint64(drop_thr(p))
+    thr = drop_thr(p)
     for b in range(B):
         for h in range(H):
-            hh = pair_hash(pid, stream_key(seed, b * H + h))
-            r = np.where(k & np.uint64(1), hh >> np.uint64(16), hh & np.uint64(0xFFFF))
-            out[b, h] = r >= thr
+            out[b, h] = keep_rows(stream_key(seed, b * H + h), Tq, Tk, thr)
     return out
 
 

@@ -34,3 +34,14 @@ def pytest_sessionfinish(session, exitstatus):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "margins.json"), "w") as f:
         json.dump(MARGINS, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(autouse=True)
+def _device_quiesced_between_tests(request):
+    """A GPU test leaves no work in flight: a device fault is then reported against the test that launched the faulting
+    kernel, not against whichever later test first synchronises."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()

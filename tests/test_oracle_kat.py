@@ -276,16 +276,18 @@ def test_dropout_generator_known_answers_and_statistics():
     step's definition when dropout is on: pin it with frozen vectors, and check that it behaves like independent
     Bernoulli draws (rate, adjacent / cross-row / cross-stream / cross-step correlation)."""
     from oracle import dropout as D
-    assert [int(D.pair_hash(i, k)) for i, k in ((0, 0), (1, 0), (12345, 0xDEADBEEF), (0xFFFFFFFF, 0x12345678))] == \
-        [0, 3944701879, 1023874381, 3419432724]
+    assert [int(D.pair_hash(D.row_key(k, r), c)) for k, r, c in
+            ((0, 0, 0), (0, 1, 0), (0xDEADBEEF, 12345, 77), (0x12345678, 0xFFFFFFFF, 0xFFFFFF))] == \
+        [2356614601, 2907385536, 1512887188, 2692573910]
+    assert [int(x) for x in D.row_key(0xDEADBEEF, 12345)] == [2238520111, 1453611697]
     assert (int(D.mix32(1)), int(D.mix32(0xDEADBEEF)), int(D.stream_key(0x0123456789ABCDEF, 7))) == \
         (1753845952, 3861431939, 1429204582)
     assert D.drop_thr(0.1) == 6554 and D.drop_thr(0.25) == 16384
     assert abs(D.keep_scale(0.1) - 65536.0 / (65536 - 6554)) < 1e-6
-    assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 1, 1, 1, 0, 1, 1, 1], [1, 0, 1, 1, 1, 1, 1, 1],
-                                                              [1, 1, 1, 0, 1, 1, 1, 1], [1, 1, 1, 1, 0, 1, 0, 1]]
+    assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 0, 1, 1, 0, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1, 0],
+                                                              [0, 1, 0, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1, 1]]
     assert D.keep_attention(42, 1, 2, 3, 6, 0.5).astype(int).tolist() == \
-        [[[[1, 0, 1, 1, 0, 1], [0, 1, 1, 0, 1, 1], [0, 1, 1, 1, 0, 0]], [[0, 1, 0, 1, 0, 0], [0, 0, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1]]]]
+        [[[[1, 0, 1, 0, 0, 1], [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 1, 1]], [[0, 1, 0, 0, 0, 0], [1, 0, 1, 0, 0, 1], [1, 0, 1, 0, 0, 0]]]]
     assert D.site_seed(0xC0FFEE, 3, 204) == 17806544269414322833
     assert D.site_id("decoder.layers.3.encoder_attn") == 403 and D.w2v_site_id("encoder.layers.11.attention_output") == 211
     m = D.keep_flat(7, 600, 768, 0.1)
@@ -303,19 +305,30 @@ def test_dropout_generator_known_answers_and_statistics():
 
 
 def test_dropout_hash_uses_every_counter_and_key_bit():
-    """ADVICE r1 (tmi_common.h:89): the pair hash multiplies 24-bit quantities; without folding the high bits in first,
-    counter pairs 2^24 apart (elements 2^25 apart: Whisper-large at batch >= 18) and stream keys equal in their low 24
-    bits draw (almost) the same masks.  With the fold the masks are independent: agreement ~ 0.9^2 + 0.1^2 = 0.82."""
+    """ADVICE r1 (tmi_common.h:89): the pair hash multiplies 24-bit quantities, so whatever must not alias has to reach
+    those 24 bits first.  Rows and stream keys go through two full 32-bit avalanches per row (tmi_row_key), columns are
+    < 2^17 by contract (TMI_DROP_MAX_COLS, checked by the entry points): rows 2^24 apart, stream keys equal in their low 24 bits, and the two draws of one pair are all
+    independent -- agreement of two independent p = 0.1 masks is 0.9^2 + 0.1^2 = 0.82."""
     from oracle import dropout as DO
     thr = DO.drop_thr(0.1)
-    idx = np.arange(1 << 18, dtype=np.uint64)
     key = DO.stream_key(0x1234567890ABCDEF, 7)
-    a = DO.keep_counter(key, idx, thr)
-    b = DO.keep_counter(key, idx + np.uint64(1 << 25), thr)
+    rows = np.arange(512, dtype=np.uint64)[:, None]
+    cols = np.arange(512, dtype=np.uint64)[None, :]
+
+    def keep(key, rows):
+        h = DO.pair_hash(DO.row_key(key, rows), cols >> np.uint64(1))
+        return np.where(cols & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xFFFF)) >= np.uint64(thr)
+
+    a = keep(key, rows)
+    assert np.array_equal(a, DO.keep_rows(key, 512, 512, thr))
+    b = keep(key, rows + np.uint64(1 << 24))
     assert abs(a.mean() - 0.9) < 3e-3 and abs(b.mean() - 0.9) < 3e-3
     assert abs((a == b).mean() - 0.82) < 5e-3
     key2 = (int(key) ^ 0xA5000000) & 0xFFFFFFFF  # differs in the top byte only
-    c = DO.keep_counter(np.uint64(key2), idx, thr)
+    c = keep(np.uint64(key2), rows)
     assert abs((a == c).mean() - 0.82) < 5e-3
-    # low and high 16-bit draws of one pair are independent too
-    assert abs((a[0::2] == a[1::2]).mean() - 0.82) < 5e-3
+    # low and high 16-bit draws of one pair are independent too, and so are columns 2^16 apart (the top of the contract)
+    assert abs((a[:, 0::2] == a[:, 1::2]).mean() - 0.82) < 5e-3
+    h0 = DO.pair_hash(DO.row_key(key, rows), cols >> np.uint64(1))
+    h1 = DO.pair_hash(DO.row_key(key, rows), (cols >> np.uint64(1)) + np.uint64(1 << 15))
+    assert abs((((h0 & np.uint64(0xFFFF)) >= np.uint64(thr)) == ((h1 & np.uint64(0xFFFF)) >= np.uint64(thr))).mean() - 0.82) < 5e-3

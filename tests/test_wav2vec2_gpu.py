@@ -322,12 +322,17 @@ def test_wav2vec2_step_with_dropout_matches_oracle_fed_the_same_masks(dev):
             assert abs(lv - lr) <= 1e-2 * abs(lr), (step, lv, lr)
             got = model.arena.ref_views(model.arena.g)
             nmax = max(float(g.norm()) for g in grads_ref.values())
-            bad = {}
+            bad, worst = {}, 0.0
+            # bf16 rounding on this tiny model is 4.6e-2 without dropout (test above); a wrong mask anywhere is an
+            # error of sqrt(2 p) ~ 0.45 in everything downstream of it, so 1e-1 still separates the two
             for k, gr in grads_ref.items():
                 err = float((got[k].double().cpu() - gr).norm() / max(float(gr.norm()), 1e-2 * nmax))
-                if err > 6e-2:
+                worst = max(worst, err)
+                if err > 1e-1:
                     bad[k] = err
-            assert not bad, (step, sorted(bad.items(), key=lambda kv: -kv[1])[:8])
+            from _margins import within
+            within(f"wav2vec2 dropout step {step} bf16 worst gradient rel L2", worst, 1e-1,  # measured 7.3e-2
+                   sorted(bad.items(), key=lambda kv: -kv[1])[:8])
     finally:
         V.DROPOUT_PROVIDER = None
     # dropout is really on: the rates-0 loss of the same batch differs

@@ -98,6 +98,8 @@ SIGNATURES = {
                                            c_i64, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_fir_groupnorm_gelu_bwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_layernorm_bwd_emit": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_f32,
+                                       C.c_uint64, c_i32, c_vp]),
     "tmi_grad_pack": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "tmi_grad_unpack": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp]),
     "tmi_contrastive_fwd_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp]),
@@ -107,7 +109,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _lib = None
 
 

@@ -266,7 +266,7 @@ class KernelBlocks:
                       bias=bias, **epi)
 
     def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False,
-                   dgrad_epi=None):
+                   dgrad_epi=None, bias_done=False):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
         ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
         before its consumer), so the dgrad goes to the weight-gradient stream too."""
@@ -280,7 +280,7 @@ class KernelBlocks:
         def weight_grads():
             ops.gemm(x2d, dy2d, dW, K_in, N, M, 1, x2d.stride(0), dy2d.stride(0), 1, N,
                      splitk=0)
-            if bname in self.arena.offsets:
+            if bname in self.arena.offsets and not bias_done:  # (bias_done: the kernel that produced dy emitted its column sums)
                 ops.bias_grad(dy2d, self.arena.grad(bname))
 
         def dgrad():
@@ -301,11 +301,23 @@ class KernelBlocks:
         ops.layernorm_fwd(x2d, a.param(pname + ".gamma"), a.param(pname + ".beta"), y2d,
                           self.ws[stat + ".mean"], self.ws[stat + ".rstd"], self.layer_norm_eps)
 
-    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate):
+    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate, emit=None):
+        """``emit`` = (bias gradient tensor, masked-copy buffer or None, dropout site or None): the Dense layer below this
+        LayerNorm takes dx (or its Dropout-masked copy) as dy; its bias gradient and the masked copy come out of this
+        kernel (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dx."""
         a = self.arena
         self._guard_write(dx2d)
-        ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
-                          dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
+        if emit is None:
+            ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
+                              dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
+            return
+        colsum, masked, site = emit
+        p = self._drop_p if (masked is not None and site is not None) else 0.0
+        if masked is not None:
+            self._guard_write(masked)
+        ops.layernorm_bwd_emit(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"], dx2d,
+                               a.grad(pname + ".gamma"), a.grad(pname + ".beta"), colsum, masked=masked if p > 0 else None,
+                               dropout_p=p, dropout_seed=self._site_seed(site) if p > 0 else 0, accumulate_dx=accumulate)
 
     # ---- dropout (training mode of the reference, W:160 / W:205 / W:342 / W:411): counter-based masks
     # regenerated in backward (tmi_dropout, tmi_attn_*).  Off unless ``enable_dropout`` was called: with

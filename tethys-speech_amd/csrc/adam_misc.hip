@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// out[r, c] = (resid ? resid[r, c] : 0) + (keep(r * cols + c) ? in[r, c] * scale : 0)      (Dropout, see tmi_common.h)
+// out[r, c] = (resid ? resid[r, c] : 0) + (keep(r, c) ? in[r, c] * scale : 0)      (Dropout, see tmi_common.h)
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ in, int64_t ld_in, const T* __restrict__ resid,
                                                       int64_t ld_res, T* __restrict__ out, int64_t ld_out, int64_t rows,
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ in, 
   const int64_t total = rows * pairs_per_row;
   for (int64_t pid = (int64_t)blockIdx.x * 256 + threadIdx.x; pid < total; pid += (int64_t)gridDim.x * 256) {
     const int64_t r = pid / pairs_per_row, c = (pid - r * pairs_per_row) * 2;
-    const uint32_t h = tmi_pair_hash((uint32_t)pid, key);
+    const uint32_t h = tmi_pair_hash(tmi_row_key(key, (uint32_t)r), (uint32_t)(c >> 1));
     const bool k0 = (h & 0xffffu) >= thr, k1 = (h >> 16) >= thr;
     float a0 = k0 ? to_f32(in[r * ld_in + c]) * scale : 0.f;
     float a1 = k1 ? to_f32(in[r * ld_in + c + 1]) * scale : 0.f;
@@ -187,12 +187,13 @@ __global__ __launch_bounds__(256) void dropout_vec_kernel(const T* __restrict__ 
   const int64_t cpr = cols >> 3, total = rows * cpr;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t r = idx / cpr, c = (idx - r * cpr) * 8;
-    const uint32_t pid0 = (uint32_t)((r * cols + c) >> 1);
+    const tmi_rowkey rk = tmi_row_key(key, (uint32_t)r);
+    const uint32_t cp0 = (uint32_t)(c >> 1);
     float v[8], t[8];
     Ld8<T>::load(in + r * ld_in + c, v);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t h = tmi_pair_hash(pid0 + j, key);
+      const uint32_t h = tmi_pair_hash(rk, cp0 + j);
       v[2 * j] = (h & 0xffffu) >= thr ? v[2 * j] * scale : 0.f;
       v[2 * j + 1] = (h >> 16) >= thr ? v[2 * j + 1] * scale : 0.f;
     }
@@ -675,7 +676,7 @@ extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, cons
 // W:411 and, applied to the incoming gradient with the same seed, their backward.  In-place (out == in) is fine.
 extern "C" int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
                            int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream) {
-  if (!in || !out || rows <= 0 || cols <= 0 || (cols & 1) || ld_in < cols || ld_out < cols || (resid && ld_res < cols) ||
+  if (!in || !out || rows <= 0 || cols <= 0 || (cols & 1) || cols > TMI_DROP_MAX_COLS || ld_in < cols || ld_out < cols || (resid && ld_res < cols) ||
       !(p >= 0.f && p < 1.f)) {
     tmi_set_error("tmi_dropout: bad argument (cols must be even, 0 <= p < 1)");
     return TMI_ERR_INVALID;

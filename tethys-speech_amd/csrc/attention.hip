@@ -198,7 +198,7 @@ struct AttnP {
   float sscale;  // scores = (q . k) * sscale
   float c2;      // sscale * log2(e)
   // dropout on the probabilities (W:160): thr == 0 is off; see tmi_common.h for the generator.  The counter of
-  // element (q, k) in stream b*H + head is q * ceil(Tk/2) * 2 + k: pairs run along k.
+  // element (q, k) of stream b*H + head: row q, column k (pairs run along k).
   uint32_t drop_thr;
   float keep_scale;
   uint32_t seed_lo, seed_hi;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   float m = -INFINITY, l = 0.f;
   const uint32_t drop_thr = P.drop_thr;
   const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
-  const uint32_t qpid = (uint32_t)q * (uint32_t)((Tk + 1) >> 1);
+  const tmi_rowkey qrk = tmi_row_key(skey, (uint32_t)q);  // the mask row of this lane's query: one avalanche per kernel
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const uint32_t hh = tmi_pair_hash(qpid + (uint32_t)((key0 + 32 * rbk + 8 * g + 4 * h) >> 1) + j, skey);
+            const uint32_t hh = tmi_pair_hash(qrk, (uint32_t)((key0 + 32 * rbk + 8 * g + 4 * h) >> 1) + j);
             if ((hh & 0xffffu) < drop_thr) s[rbk][4 * g + 2 * j] = 0.f;
             if ((hh >> 16) < drop_thr) s[rbk][4 * g + 2 * j + 1] = 0.f;
           }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   const uint32_t drop_thr = P.drop_thr;
   const float keep_scale = P.keep_scale;
   const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
-  const uint32_t qpid = (uint32_t)q * (uint32_t)((Tk + 1) >> 1);
+  const tmi_rowkey qrk = tmi_row_key(skey, (uint32_t)q);  // the mask row of this lane's query: one avalanche per kernel
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
         else return dp[e];
       };
       auto pair_draw = [&](int e) -> uint32_t {  // e even
-        if constexpr (DROP) return tmi_pair_hash(qpid + (uint32_t)((key0 + 32 * rbk + 8 * (e >> 2) + 4 * h) >> 1) + ((e >> 1) & 1), skey);
+        if constexpr (DROP) return tmi_pair_hash(qrk, (uint32_t)((key0 + 32 * rbk + 8 * (e >> 2) + 4 * h) >> 1) + ((e >> 1) & 1));
         else return 0u;
       };
       if constexpr (!edge) {
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
 }
 
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
-constexpr int NCONST = 4;  // per streamed query row: m, 1/l, delta, -(m + log2 l)
+constexpr int NCONST = 6;  // per streamed query row: m, 1/l, delta, -(m + log2 l), the two dropout row-key words (bits)
 template <bool DROP, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][NCONST][64] floats
@@ -524,10 +524,16 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   const uint32_t drop_thr = P.drop_thr;
   const float keep_scale = P.keep_scale;
   const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
-  const uint32_t kp = (uint32_t)((Tk + 1) >> 1), khalf = (uint32_t)key >> 1, ksh = ((uint32_t)key & 1u) * 16u;
-  auto keep_at = [&](uint32_t qi) -> bool {  // this lane's key against query row qi
-    const uint32_t hh = tmi_pair_hash(qi * kp + khalf, skey);
+  const uint32_t khalf = (uint32_t)key >> 1, ksh = ((uint32_t)key & 1u) * 16u;
+  auto keep_at = [&](float ra, float rb) -> bool {  // this lane's key against the query row whose mask-row key is (ra, rb)
+    const uint32_t hh = tmi_pair_hash(tmi_rowkey{__float_as_uint(ra), __float_as_uint(rb)}, khalf);
     return ((hh >> ksh) & 0xffffu) >= drop_thr;
+  };
+  // row keys of the 64 streamed query rows: one thread each, next to the softmax constants in LDS
+  auto put_row_keys = [&](float* dst, int row0) {  // threads 0..63
+    const tmi_rowkey rk = tmi_row_key(skey, (uint32_t)(row0 + (int)threadIdx.x));
+    dst[256 + threadIdx.x] = __uint_as_float(rk.a);
+    dst[320 + threadIdx.x] = __uint_as_float(rk.b);
   };
 
   // per-tile row constants: thread t carries (which = t / 64, row = t % 64)
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
     float x0, x1;
     load_consts(0, x0, x1);
     rowc_base[threadIdx.x] = make_const(x0, x1);
+    if (DROP && threadIdx.x < 64) put_row_keys(rowc_base, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -585,12 +592,17 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
           const int r = 32 * rbk + 8 * g + 4 * h;
           const f32x4 nM = *reinterpret_cast<const f32x4*>(rowc + 192 + r);
           const f32x4 dl = *reinterpret_cast<const f32x4*>(rowc + 128 + r);
+          f32x4 ra4 = f32x4{0.f, 0.f, 0.f, 0.f}, rb4 = ra4;
+          if constexpr (DROP) {
+            ra4 = *reinterpret_cast<const f32x4*>(rowc + 256 + r);
+            rb4 = *reinterpret_cast<const f32x4*>(rowc + 320 + r);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * g + i;
             const float pe = ex2(fmaf(s[e], c2, nM[i]));
             if constexpr (DROP) {  // dV sees the dropped probabilities, dS the masked dP: ds = p * (mask/keep * dp - delta)
-              const bool keep = keep_at((uint32_t)(q0 + r + i));
+              const bool keep = keep_at(ra4[i], rb4[i]);
               s[e] = keep ? pe : 0.f;
               ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - dl[i]);
             } else {
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
           if (causal && key <= qi) x = x + MASKED2;
           const float pe = (qi < Tq) ? ex2(x - rowc[r]) * rowc[64 + r] : 0.f;
           if constexpr (DROP) {
-            const bool keep = keep_at((uint32_t)qi);
+            const bool keep = keep_at(rowc[256 + r], rowc[320 + r]);
             s[e] = keep ? pe : 0.f;
             ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - rowc[128 + r]);
           } else {
@@ -620,7 +632,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
       second_product(Oimg, 32 * rbk, s, dv, lane);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
       second_product(Qimg, 32 * rbk, ds, dk, lane);  // dKt[d][key] += sum_q Q[q][d] dS[q][key]
     }
-    if (more) rowc_base[(cur ^ 1) * (NCONST * 64) + threadIdx.x] = make_const(cn0, cn1);
+    if (more) {
+      rowc_base[(cur ^ 1) * (NCONST * 64) + threadIdx.x] = make_const(cn0, cn1);
+      if (DROP && threadIdx.x < 64) put_row_keys(rowc_base + (cur ^ 1) * (NCONST * 64), (tile + 1) * TROWS);
+    }
     PIN(cn0);  // the compiler's wait for these two loads belongs here, on every path, not after the
     PIN(cn1);  // next iteration's DMA issue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -658,7 +673,8 @@ void set_dropout(AttnP& P) {
 
 int check_common(const tmi_attn_desc& d) {
   if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
-      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && d.dropout_p < 1.f))
+      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && d.dropout_p < 1.f) ||
+      (d.dropout_p > 0.f && d.Tk > TMI_DROP_MAX_COLS))
     return 0;
   return ok_mat(d.q, d.q_sb, d.q_st) && ok_mat(d.k, d.k_sb, d.k_st) && ok_mat(d.v, d.v_sb, d.v_st) &&
          ok_mat(d.o, d.o_sb, d.o_st);

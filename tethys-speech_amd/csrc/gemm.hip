@@ -276,8 +276,8 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
       return TMI_ERR_INVALID;
     }
   }
-  if (!(d.dropout_p >= 0.f && d.dropout_p < 1.f) || (d.dropout_p > 0.f && (d.nbatch != 1 || d.splitk != 1 || (d.N & 1)))) {
-    tmi_set_error("tmi_gemm: epilogue dropout needs 0 <= p < 1, nbatch == 1, splitk == 1 and an even N");
+  if (!(d.dropout_p >= 0.f && d.dropout_p < 1.f) || (d.dropout_p > 0.f && (d.nbatch != 1 || d.splitk != 1 || (d.N & 1) || d.N > TMI_DROP_MAX_COLS))) {
+    tmi_set_error("tmi_gemm: epilogue dropout needs 0 <= p < 1, nbatch == 1, splitk == 1 and an even N <= 2^17");
     return TMI_ERR_INVALID;
   }
   if (d.act != 0 && d.act != 1) {

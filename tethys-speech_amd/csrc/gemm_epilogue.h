@@ -36,7 +36,7 @@ __device__ __forceinline__ void gemm_epilogue(const tmi_gemm_desc& d, f32x16 (&a
         if (aux_out) aux_out[idx] = from_f32<TC>(v);
         if (d.act == 1) v = gelu_fwd_t<TC>(v);
         if (aux_in) v *= gelu_grad_t<TC>(to_f32(aux_in[idx]));
-        if (drop_thr) v = tmi_drop1(v, m, n, d.N, drop_key, drop_thr, drop_scale);
+        if (drop_thr) v = tmi_drop1(v, m, n, drop_key, drop_thr, drop_scale);
         if (resid) v += to_f32(resid[m * d.r_ld + n]);
         C[idx] = from_f32<TC>(v);
       }

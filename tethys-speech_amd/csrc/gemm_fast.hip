@@ -288,7 +288,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
       }
-      if (P.drop_thr) tmi_drop8(v, m, n, d.N, P.drop_key, P.drop_thr, P.drop_scale);
+      if (P.drop_thr) tmi_drop8(v, m, n, P.drop_key, P.drop_thr, P.drop_scale);
       if (resid) {
         Vec8<TC>::load(resid + m * d.r_ld + n, t);
 #pragma unroll
@@ -304,7 +304,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
         if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
         if (d.act == 1) x = gelu_fwd_t<TC>(x);
         if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
-        if (P.drop_thr) x = tmi_drop1(x, m, n + i, d.N, P.drop_key, P.drop_thr, P.drop_scale);
+        if (P.drop_thr) x = tmi_drop1(x, m, n + i, P.drop_key, P.drop_thr, P.drop_scale);
         if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
         C[idx + i] = from_f32<TC>(x);
       }
@@ -375,7 +375,7 @@ __device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x1
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
       }
-      if (P.drop_thr) tmi_drop8(v, m, n, d.N, P.drop_key, P.drop_thr, P.drop_scale);
+      if (P.drop_thr) tmi_drop8(v, m, n, P.drop_key, P.drop_thr, P.drop_scale);
       if (resid) {
         Vec8<TC>::load(resid + m * d.r_ld + n, t);
 #pragma unroll
@@ -391,7 +391,7 @@ __device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x1
         if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
         if (d.act == 1) x = gelu_fwd_t<TC>(x);
         if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
-        if (P.drop_thr) x = tmi_drop1(x, m, n + i, d.N, P.drop_key, P.drop_thr, P.drop_scale);
+        if (P.drop_thr) x = tmi_drop1(x, m, n + i, P.drop_key, P.drop_thr, P.drop_scale);
         if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
         C[idx + i] = from_f32<TC>(x);
       }

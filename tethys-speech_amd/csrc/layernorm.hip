@@ -112,22 +112,32 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // blocks at C = 768), so the grid is kept to about one block per CU and each block starts its
 // column walk at a different offset.
 constexpr int LNB_WAVES = 8;
-template <typename T, int NCH>
+template <typename T, int NCH, bool EMIT = false>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C,
-                                                     int accumulate_dx) {
+                                                     int accumulate_dx, float* __restrict__ colsum, T* __restrict__ masked,
+                                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale) {
+  // EMIT: the residual-stream gradient this kernel writes (dx) is the dy of the Dense layer below it, whose bias
+  // gradient is its column sum - and, where that layer's output went through Dropout (W:205, V:396, V:431), the dy is
+  // the MASKED dx.  Both come out of this pass: colsum[c] += sum_rows (masked ? mask*dx : dx), masked[row][c] = mask*dx,
+  // instead of a dropout kernel and a column-sum kernel re-reading dx.
   using IO = RowIO<T, NCH>;
   constexpr int E = IO::E;
+  constexpr int NRED = EMIT ? 3 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [8 waves][2][C]
+  float* red = reinterpret_cast<float*>(smem);  // [8 waves][NRED][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float g[E], dg[E], db[E];
+  float g[E], dg[E], db[E], dc[EMIT ? E : 1];
   IO::load_f32vec(gamma, C, lane, g);
 #pragma unroll
   for (int i = 0; i < E; ++i) dg[i] = db[i] = 0.f;
+  if constexpr (EMIT) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) dc[i] = 0.f;
+  }
   const float invC = 1.0f / (float)C;
   const int64_t step = (int64_t)gridDim.x * LNB_WAVES;
   int64_t row = (int64_t)blockIdx.x * LNB_WAVES + wave;
@@ -179,6 +189,26 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
       dv[e] = r;
     }
     IO::store(dx + row * C, C, lane, dv);
+    if constexpr (EMIT) {
+      if (masked) {
+        const tmi_rowkey rk = tmi_row_key(drop_key, (uint32_t)row);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          const int c0 = (j * 64 + lane) * IO::VEC;
+          const uint32_t cp0 = (uint32_t)(c0 >> 1);
+#pragma unroll
+          for (int i = 0; i < IO::VEC; i += 2) {
+            const uint32_t hh = tmi_pair_hash(rk, cp0 + (i >> 1));
+            const int e = j * IO::VEC + i;
+            dv[e] = (hh & 0xffffu) >= drop_thr ? dv[e] * drop_scale : 0.f;
+            dv[e + 1] = (hh >> 16) >= drop_thr ? dv[e + 1] * drop_scale : 0.f;
+          }
+        }
+        IO::store(masked + row * C, C, lane, dv);
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) dc[e] += dv[e];
+    }
   }
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
@@ -186,8 +216,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     if (c0 < C) {
 #pragma unroll
       for (int i = 0; i < IO::VEC; ++i) {
-        red[(wave * 2 + 0) * C + c0 + i] = dg[j * IO::VEC + i];
-        red[(wave * 2 + 1) * C + c0 + i] = db[j * IO::VEC + i];
+        red[(wave * NRED + 0) * C + c0 + i] = dg[j * IO::VEC + i];
+        red[(wave * NRED + 1) * C + c0 + i] = db[j * IO::VEC + i];
+        if constexpr (EMIT) red[(wave * NRED + 2) * C + c0 + i] = dc[j * IO::VEC + i];
       }
     }
   }
@@ -196,14 +227,16 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
   for (int i = threadIdx.x; i < C; i += 64 * LNB_WAVES) {
     int c = start + i;
     c = c >= C ? c - C : c;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, cc = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_WAVES; ++w) {
-      a += red[(w * 2 + 0) * C + c];
-      b += red[(w * 2 + 1) * C + c];
+      a += red[(w * NRED + 0) * C + c];
+      b += red[(w * NRED + 1) * C + c];
+      if constexpr (EMIT) cc += red[(w * NRED + 2) * C + c];
     }
     atomicAdd(dgamma + c, a);
     atomicAdd(dbeta + c, b);
+    if constexpr (EMIT) atomicAdd(colsum + c, cc);
   }
 }
 
@@ -327,12 +360,13 @@ extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float*
   return tmi_check_launch("tmi_layernorm_fwd");
 }
 
-extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
-                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
-                                 int32_t accumulate_dx, int32_t dtype, void* stream) {
+static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                         float* dgamma, float* dbeta, int64_t rows, int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
+                         float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream, const char* what) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
-      C % vec || !al16(x) || !al16(dy) || !al16(dx)) {
+      C % vec || !al16(x) || !al16(dy) || !al16(dx) || (masked && (!colsum || !al16(masked) || (C & 1))) ||
+      !(dropout_p >= 0.f && dropout_p < 1.f)) {
     tmi_set_error("tmi_layernorm_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
@@ -341,29 +375,59 @@ extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gam
   int64_t rpw = (rows + LNB_WAVES * cap_b - 1) / (LNB_WAVES * cap_b);
   if (rpw < 2) rpw = 2;  // amortise the per-block dgamma/dbeta fold
   const int64_t blocks = (rows + LNB_WAVES * rpw - 1) / (LNB_WAVES * rpw);
-  const size_t lds = (size_t)LNB_WAVES * 2 * C * sizeof(float);  // <= 128 KiB at C = 2048
+  const bool emit = colsum != nullptr;
+  const size_t lds = (size_t)LNB_WAVES * (emit ? 3 : 2) * C * sizeof(float);  // <= 128 KiB (192 with emission) at C = 2048
+  if (emit && lds > 160 * 1024) {
+    tmi_set_error("tmi_layernorm_bwd_emit: C too wide for the three-way fold");
+    return TMI_ERR_INVALID;
+  }
+  const uint32_t thr = masked ? tmi_drop_thr(dropout_p) : 0u;
+  const uint32_t key = tmi_stream_key(dropout_seed, 0u);
+  const float scale = tmi_keep_scale(thr);
+  void* mk = (masked && thr) ? masked : nullptr;  // p == 0: the "masked" copy is dx itself; only the column sum is emitted
+  auto go = [&](auto tag_t, auto nch, auto em) {
+    using T = decltype(tag_t);
+    constexpr int N = decltype(nch)::value;
+    constexpr bool EM = decltype(em)::value;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<T, N, EM>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * (EM ? 3 : 2) * LN_MAX_C * 4 > 160 * 1024 ? 160 * 1024 : LNB_WAVES * (EM ? 3 : 2) * LN_MAX_C * 4);
+    (void)attr;
+    hipLaunchKernelGGL((ln_bwd_kernel<T, N, EM>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s, (const T*)dy, (const T*)x,
+                       gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx, colsum, (T*)mk, key, thr, scale);
+  };
   if (dtype == TMI_BF16) {
     ln_dispatch<bf16_t>(C, [&](auto nch) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<bf16_t, decltype(nch)::value>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
-      (void)attr;
-      hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
-                         (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, dgamma, dbeta, rows, (int)C,
-                         accumulate_dx);
+      if (emit) go(bf16_t{}, nch, std::true_type{});
+      else go(bf16_t{}, nch, std::false_type{});
     });
   } else if (dtype == TMI_F32) {
     ln_dispatch<float>(C, [&](auto nch) {
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<float, decltype(nch)::value>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * 2 * LN_MAX_C * 4);
-      (void)attr;
-      hipLaunchKernelGGL((ln_bwd_kernel<float, decltype(nch)::value>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s,
-                         (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, rows, (int)C,
-                         accumulate_dx);
+      if (emit) go(float{}, nch, std::true_type{});
+      else go(float{}, nch, std::false_type{});
     });
   } else {
     return TMI_ERR_UNSUPPORTED;
   }
-  return tmi_check_launch("tmi_layernorm_bwd");
+  return tmi_check_launch(what);
+}
+
+extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                 int32_t accumulate_dx, int32_t dtype, void* stream) {
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, nullptr, nullptr, 0.f, 0, dtype, stream,
+                       "tmi_layernorm_bwd");
+}
+
+extern "C" int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                      int32_t accumulate_dx, float* colsum, void* masked, float dropout_p,
+                                      uint64_t dropout_seed, int32_t dtype, void* stream) {
+  if (!colsum) {
+    tmi_set_error("tmi_layernorm_bwd_emit: colsum is required");
+    return TMI_ERR_INVALID;
+  }
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, colsum, masked, dropout_p, dropout_seed,
+                       dtype, stream, "tmi_layernorm_bwd_emit");
 }
 
 extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,

@@ -69,17 +69,21 @@ template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
 
 // ---- counter-based dropout (tf.keras.layers.Dropout sites W:160, W:205, W:342, W:411 in training).
 // TF's stateful RNG stream cannot be reproduced; the keep decision here is a pure function of
-// (seed, site-local element counter), so forward and backward regenerate the same mask and nothing is
-// stored.  One 32-bit hash serves the two elements of a counter pair (16 bits each): element e is dropped
-// when its 16-bit draw is < thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr), the
-// exact inverse of the keep probability.  The oracle restates the same integer arithmetic (oracle/dropout.py).
+// (seed, stream, row, column) of the tensor the Dropout layer sees, so forward and backward regenerate the same mask
+// and nothing is stored.  Two levels, so that the per-element cost is five full-rate VALU instructions per TWO elements:
+//   row key   (ra, rb) = (mix32(key ^ row * 0x9E3779B1), mix32((key + 0x632BE5AB) ^ row * 0x85EBCA6B))
+//                        two full avalanches per ROW (once per lane in the attention kernels): every bit of seed,
+//                        stream and row reaches both words
+//   pair hash x = ra ^ (column >> 1);  h = mul24(x, 0x9E3779);  h ^= (h >> 15) ^ rb;  h = mul24(h, 0x85EBCB)
+// (v_mul_u32_u24 is a full-rate VALU instruction, the 32-bit v_mul_lo_u32 is quarter rate; v_xor3_b32 takes the two
+// xors).  The low / high 16 bits of h are the draws of the even / odd column of the pair: an element is dropped when its
+// draw is < thr = round(p * 65536); kept values are scaled by 65536 / (65536 - thr), the exact inverse of the keep
+// probability.  Columns < TMI_DROP_MAX_COLS = 2^17 (above that the multiplicative pair hash starts to correlate columns
+// 2^17 apart; the entry points refuse wider masks), rows < 2^32.  The oracle restates the same integer arithmetic (oracle/dropout.py).
 __host__ __device__ __forceinline__ uint32_t tmi_mix32(uint32_t x) {  // "lowbias32" finaliser
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-// pair hash: 32 bits for the counter pair `pid` of a stream with key `key`.  Built on 24-bit multiplies
-// (v_mul_u32_u24 / v_mad_u32_u24 are full-rate VALU instructions, the 32-bit v_mul_lo_u32 is quarter rate): seven
-// instructions per two elements inside the attention kernels, which are VALU-bound.
 __host__ __device__ __forceinline__ uint32_t tmi_mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __umul24(a, b);
@@ -87,41 +91,43 @@ __host__ __device__ __forceinline__ uint32_t tmi_mul24(uint32_t a, uint32_t b) {
   return (uint32_t)((uint64_t)(a & 0xffffffu) * (uint64_t)(b & 0xffffffu));
 #endif
 }
-__host__ __device__ __forceinline__ uint32_t tmi_pair_hash(uint32_t pid, uint32_t key) {
-  uint32_t a = pid ^ key;
-  a ^= a >> 17;  // the 24-bit multiplier sees only bits 0..23: fold 17..31 in first, so that counter pairs 2^24 apart
-                 // (tensors beyond 2^25 elements: Whisper-large at batch >= 18) and keys that differ only in their
-                 // top byte draw different masks
-  uint32_t h = tmi_mul24(a, 0x9E3779u);
-  h ^= h >> 15;
-  return tmi_mul24(h, 0x85EBCBu) + (a >> 8);
+constexpr int64_t TMI_DROP_MAX_COLS = 1 << 17;
+struct tmi_rowkey { uint32_t a, b; };
+__host__ __device__ __forceinline__ tmi_rowkey tmi_row_key(uint32_t stream_key, uint32_t row) {
+  return tmi_rowkey{tmi_mix32(stream_key ^ (row * 0x9E3779B1u)), tmi_mix32((stream_key + 0x632BE5ABu) ^ (row * 0x85EBCA6Bu))};
+}
+// 32 bits for column pair `cp` (= column >> 1) of the row with key `rk`
+__host__ __device__ __forceinline__ uint32_t tmi_pair_hash(tmi_rowkey rk, uint32_t cp) {
+  uint32_t h = tmi_mul24(rk.a ^ cp, 0x9E3779u);
+  h = h ^ (h >> 15) ^ rk.b;
+  return tmi_mul24(h, 0x85EBCBu);
 }
 __host__ __device__ __forceinline__ uint32_t tmi_drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 __host__ __device__ __forceinline__ float tmi_keep_scale(uint32_t thr) { return 65536.0f / (float)(65536u - thr); }
-// key of a stream of counters: seed (64 bit) and a 32-bit stream id (e.g. batch*heads + head; 0 for flat tensors)
+// key of a stream: seed (64 bit) and a 32-bit stream id (batch*heads + head for attention; 0 for flat tensors)
 __host__ __device__ __forceinline__ uint32_t tmi_stream_key(uint64_t seed, uint32_t stream_id) {
   return tmi_mix32((uint32_t)seed ^ tmi_mix32((uint32_t)(seed >> 32) + stream_id));
 }
-// keep decision of element `idx` (flat counter < 2^33) of a stream
-__host__ __device__ __forceinline__ bool tmi_keep(uint32_t key, uint64_t idx, uint32_t thr) {
-  const uint32_t h = tmi_pair_hash((uint32_t)(idx >> 1), key);
-  const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+// keep decision of element (row, col) of a stream
+__host__ __device__ __forceinline__ bool tmi_keep(uint32_t stream_key, uint32_t row, uint32_t col, uint32_t thr) {
+  const uint32_t h = tmi_pair_hash(tmi_row_key(stream_key, row), col >> 1);
+  const uint32_t r = (col & 1) ? (h >> 16) : (h & 0xffffu);
   return r >= thr;
 }
 
 // dropout term of a GEMM epilogue (tmi_gemm_desc.dropout_p): 8 consecutive columns n .. n+7 (n even) of output row m
-__device__ __forceinline__ void tmi_drop8(float (&v)[8], int64_t m, int64_t n, int64_t N, uint32_t key, uint32_t thr,
-                                          float scale) {
-  const uint32_t pid0 = (uint32_t)((m * N + n) >> 1);
+__device__ __forceinline__ void tmi_drop8(float (&v)[8], int64_t m, int64_t n, uint32_t key, uint32_t thr, float scale) {
+  const tmi_rowkey rk = tmi_row_key(key, (uint32_t)m);
+  const uint32_t cp0 = (uint32_t)(n >> 1);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const uint32_t h = tmi_pair_hash(pid0 + j, key);
+    const uint32_t h = tmi_pair_hash(rk, cp0 + j);
     v[2 * j] = (h & 0xffffu) >= thr ? v[2 * j] * scale : 0.f;
     v[2 * j + 1] = (h >> 16) >= thr ? v[2 * j + 1] * scale : 0.f;
   }
 }
-__device__ __forceinline__ float tmi_drop1(float v, int64_t m, int64_t n, int64_t N, uint32_t key, uint32_t thr, float scale) {
-  return tmi_keep(key, (uint64_t)(m * N + n), thr) ? v * scale : 0.f;
+__device__ __forceinline__ float tmi_drop1(float v, int64_t m, int64_t n, uint32_t key, uint32_t thr, float scale) {
+  return tmi_keep(key, (uint32_t)m, (uint32_t)n, thr) ? v * scale : 0.f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

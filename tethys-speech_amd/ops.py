@@ -183,6 +183,20 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, accumulate_
                                       1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
 
 
+def layernorm_bwd_emit(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, colsum, masked=None, dropout_p=0.0, dropout_seed=0,
+                       accumulate_dx=False):
+    """layernorm_bwd that also accumulates colsum[c] += sum_rows dy' and (with ``masked``) writes dy' = Dropout-mask(dx):
+    what the Dense layer below needs of dx (tmi_layernorm_bwd_emit)."""
+    es = x2d.element_size()
+    work = ((4.0 if accumulate_dx else 3.0) + (1.0 if masked is not None and dropout_p > 0 else 0.0)) * x2d.numel() * es
+    with _probe("layernorm", work):
+        rows, Cn = x2d.shape
+        check(lib().tmi_layernorm_bwd_emit(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                           dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
+                                           1 if accumulate_dx else 0, colsum.data_ptr(), ptr(masked), dropout_p, dropout_seed,
+                                           dt(x2d), stream()), "tmi_layernorm_bwd_emit")
+
+
 def bias_grad(dy2d, dbias):
     """dbias[N] += sum over rows of dy2d[rows, N] (atomics: zero dbias first)."""
     with _probe("colsum", 1.0 * dy2d.numel() * dy2d.element_size()):

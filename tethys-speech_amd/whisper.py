@@ -537,7 +537,24 @@ class WhisperForConditionalGeneration(KernelBlocks):
             ops.cast_bf16(acc, d, dtmp, d, B * S, d)
         else:
             ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
-        self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False)
+        # Column sums (bias gradients) and Dropout-masked copies of the residual-stream gradient come out of the LayerNorm
+        # backward that produces it (tmi_layernorm_bwd_emit): ffn_emit(side, i) = what layer i's fc2 needs of the dres
+        # handed down to it - its bias gradient and, with dropout, dres under the mask of W:205 in one of two
+        # alternating buffers (a layer's weight gradient on the second stream may still be reading the other one)
+        emit_on = os.environ.get("TMI_LN_EMIT", "1") != "0"
+
+        def ffn_emit(side, i, rows):
+            if not emit_on or i < 0:
+                return None
+            pre = f"{'encoder' if side == 'enc' else 'decoder'}.layers.{i}.feed_forward.fc2.bias"
+            site = (SITE_ENC_FFN if side == "enc" else SITE_DEC_FFN) + i
+            return (a.grad(pre), ws[f"dyd{i & 1}"][:rows] if drop else None, site)
+
+        def bias_emit(name):
+            return (a.grad(name), None, None) if emit_on else None
+
+        Ld = cfg.decoder_layers
+        self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False, emit=ffn_emit("dec", Ld - 1, B * S))
         ready("decoder.layer_norm.gamma")
 
         d_enc, dkv = ws["d_enc_out"], ws["dkv_all"]
@@ -558,12 +575,14 @@ class WhisperForConditionalGeneration(KernelBlocks):
             dy = dres
             if drop:
                 dy = ws[f"dyd{i & 1}"][:Rd]
-                self._dropout(dres, dy, SITE_DEC_FFN + i)
-            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+                if not emit_on:
+                    self._dropout(dres, dy, SITE_DEC_FFN + i)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on)
             self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
-            self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True)
+            self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True,
+                         emit=bias_emit(p + ".encoder_attn.out_proj.bias"))
             # cross attention
-            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctx)
+            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctx, bias_done=emit_on)
             dqc = ws["dtmp"][:Rd]
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
                            (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctx, (dqc, 0),
@@ -582,14 +601,15 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 self._run_on_side(kv_backward, dkv[:, 2 * i * d:])
             dxn2 = ws["dctx"][:Rd]
             self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
-            self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True)
+            self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True,
+                         emit=bias_emit(p + ".self_attn.out_proj.bias"))
             # self attention
-            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
+            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on)
             qkv = ws[k + "qkv"]
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
-            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True, emit=ffn_emit("dec", i - 1, Rd))
             ready(p + ".self_attn_layer_norm.gamma")
         if cfg.decoder_layers:
             if kv_per_layer:
@@ -608,25 +628,28 @@ class WhisperForConditionalGeneration(KernelBlocks):
         dres = ws["dres_enc"]
         if cfg.decoder_layers == 0:
             d_enc.zero_()
-        self._ln_bwd(d_enc, ws["enc_x"], "encoder.layer_norm", dres, "enc_ln", False)
-        ready("encoder.layer_norm.gamma")
         R = B * T
+        self._ln_bwd(d_enc, ws["enc_x"], "encoder.layer_norm", dres, "enc_ln", False,
+                     emit=ffn_emit("enc", cfg.encoder_layers - 1, R))
+        ready("encoder.layer_norm.gamma")
         for i in reversed(range(cfg.encoder_layers)):
             p, k = f"encoder.layers.{i}", f"enc{i}."
             dU, dt_, dctx, dqkv = ws["dU"][:R], ws["dtmp"][:R], ws["dctx"][:R], ws["dqkv"][:R]
             dy = dres
             if drop:
                 dy = ws[f"dyd{i & 1}"][:R]
-                self._dropout(dres, dy, SITE_ENC_FFN + i)
-            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"])
+                if not emit_on:
+                    self._dropout(dres, dy, SITE_ENC_FFN + i)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on)
             self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_)
-            self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True)
-            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx)
+            self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True,
+                         emit=bias_emit(p + ".self_attn.out_proj.bias"))
+            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on)
             qkv = ws[k + "qkv"]
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0, site=SITE_ENC_ATTN + i)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
-            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True)
+            self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True, emit=ffn_emit("enc", i - 1, R))
             ready(p + ".self_attn_layer_norm.gamma")
 
         # ---- stem backward: x0 = gelu(u2) + PE ; u2 = conv2(h1) ; h1 = gelu(u1) ; u1 = conv1(x)
