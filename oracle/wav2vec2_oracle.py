@@ -468,3 +468,33 @@ def train_steps_single(cfg, params, pool, batch_size, num_steps, seed=42, lr=3e-
         adam_step(params, g, state, lr=lr, eps=1e-7)
         losses.append(float(loss))
     return losses, state
+
+
+def train_steps_stable(cfg, params, pool, batch_per_replica, world, num_steps, seed=42, lr=3e-5):
+    """stable_jobs/wav2vec2_dist.py ("T:") - the S: model and step under MultiWorkerMirroredStrategy (T:1143-1190, T:1193-1268):
+    ``create_dummy_dataset(GLOBAL_BATCH).batch().repeat()`` keeps the short last batch (T:1094-1111); replica r takes rows
+    [r*B, (r+1)*B) of each global batch (possibly fewer, possibly none); each replica's loss is the mean over ITS rows, the
+    gradients are SUMMED over replicas (no 1/N, T:1183), Adam eps 1e-7 with nothing clipped (T:1200); the printed loss is
+    the SUM of the replica losses (T:1190).  One permutation draw per replica per step, in rank order.  A replica with no
+    rows contributes zero gradient and zero loss (the reference's arithmetic has no defined value there: a mean over an
+    empty batch)."""
+    rng = np.random.default_rng(seed)
+    T = feature_lengths(cfg, pool.shape[1])[-1]
+    it = batches_keep_remainder(pool, batch_per_replica * world)
+    state = AdamState()
+    losses = []
+    for _ in range(num_steps):
+        a = next(it)
+        total, lsum = None, 0.0
+        for r in range(world):
+            neg = torch.from_numpy(sample_negative_indices_roll(rng, T, cfg.num_negatives))
+            rows = a[r * batch_per_replica:(r + 1) * batch_per_replica]
+            if rows.shape[0] == 0:
+                continue
+            loss, g, _ = loss_and_grads_single(params, torch.from_numpy(rows), neg, cfg)
+            lsum += float(loss)
+            total = g if total is None else {k: total[k] + g[k] for k in g}
+        adam_step(params, total, state, lr=lr, eps=1e-7)
+        losses.append(lsum)
+    return losses, state
+

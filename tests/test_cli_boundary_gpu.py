@@ -50,7 +50,13 @@ def _job(which, ttype, tindex, port, ws, res, q):
     os.environ["TETHYS_WORKSPACE"], os.environ["TETHYS_RESULT"] = ws, res
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        if which == "whisper":
+        if which == "stable_w2v":
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("stable_wav2vec2_dist", os.path.join(ROOT, "stable_jobs", "wav2vec2_dist.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            rc = mod.main(["--batch_size", "2", "--num_batches", "3"], model_overrides=V_OVER, train_kw=dict(clip_samples=800))
+        elif which == "whisper":
             import whisper_dist
             rc = whisper_dist.main(["--batch_size", "2", "--num_batches", "3"], model_overrides=W_OVER,
                                    train_kw=dict(seq_len=96, max_target_length=12))
@@ -148,3 +154,42 @@ def test_whisper_single_main(dev, tmp_path, monkeypatch, capsys):
     assert tail == [f"모델이 {os.path.join(ws, 'model_cache', 'wav2vec2_model')}에 저장되었습니다.", ""]
     assert open(os.path.join(res, "jobname", "single_jct.txt")).read() == "%.2f" % jct
     assert all(l == l for l in losses)
+
+
+def test_stable_wav2vec2_dist_main_chief_and_worker(dev, tmp_path):
+    """stable_jobs/wav2vec2_dist.py (T:1271-1339): banner, step lines, jct file, the model-saved line."""
+    ws, res, out = _run_pair("stable_w2v", tmp_path)
+    losses = {}
+    for t in ("chief", "worker"):
+        rc, txt = out[t]
+        assert rc == 0
+        lines = txt.split("\n")
+        head = ["batch size per replica: 2, global batch size: 4", "num_batches: 3", "Wav2Vec2 분산 학습 시작..."] + BANNER
+        tail, jct, losses[t] = _check_common(lines, head, 3)
+        assert tail == [f"모델이 {os.path.join(ws, 'model_cache', 'wav2vec2_model')}에 저장되었습니다.", ""]
+        assert open(os.path.join(res, "jobname", f"{t}_0_jct.txt")).read() == "%.2f" % jct
+    assert losses["chief"] == losses["worker"]
+
+
+def test_wav2vec2_single_main(dev, tmp_path, monkeypatch, capsys):
+    """speech_jobs/wav2vec2_single.py (U:1279-1349): its own banner and closing lines, no result file."""
+    sys.path.insert(0, os.path.join(ROOT, "speech_jobs"))
+    ws = str(tmp_path / "w")
+    os.makedirs(ws)
+    monkeypatch.setenv("TETHYS_WORKSPACE", ws)
+    monkeypatch.delenv("TF_CONFIG", raising=False)
+    import wav2vec2_single
+    rc = wav2vec2_single.main(["--batch_size", "2", "--num_batches", "3", "--model_size", "tiny"], model_overrides=V_OVER,
+                              train_kw=dict(clip_samples=800))
+    assert rc == 0
+    lines = capsys.readouterr().out.split("\n")
+    assert lines[:7] == ["Wav2Vec2 단일 GPU 학습 시작...", "선택된 모델 크기: tiny", "선택된 모델 타입: pretraining",
+                         "Tiny 모델: 약 15-20M 파라미터", "모델 가중치 초기화 중...", "모델 가중치 초기화 완료", "에포크 1/1"]
+    for i, l in enumerate(lines[7:10]):
+        m = STEP_RE.match(l)
+        assert m and int(m.group(1)) == i, l
+    assert lines[10] == "학습 완료." and re.match(r"^JCT: \d+\.\d+$", lines[11])
+    assert lines[12:] == [f"Tiny pretraining 모델이 {os.path.join(ws, 'model_cache', 'wav2vec2_tiny_pretraining_model')}에 저장되었습니다.", ""]
+    with pytest.raises(SystemExit):
+        wav2vec2_single.main(["--model_type", "asr"])
+

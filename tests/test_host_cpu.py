@@ -362,3 +362,33 @@ def test_bench_timing_logic_two_rank_gloo():
     for step in range(7):                                    # 2 warm-up + 5 timed global batches of 8
         s = (step % 6) * 8
         assert np.array_equal(seen0[step], f[s:s + 4, 0, 0]) and np.array_equal(seen1[step], f[s + 4:s + 8, 0, 0])
+
+
+def test_stable_jobs_whisper_dist_is_the_speech_jobs_entry_point():
+    """stable_jobs/whisper_dist.py is byte-identical to speech_jobs/whisper_dist.py in the reference: one main()."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stable_whisper_dist", os.path.join(root, "stable_jobs", "whisper_dist.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from speech_jobs import whisper_dist
+    assert mod.main is whisper_dist.main
+
+
+def test_w2v_dataset_keeps_the_short_batch_across_replicas():
+    """stable_jobs/wav2vec2_dist.py:1094-1111, 1226: batch(GLOBAL).repeat() over 50 clips without drop_remainder; replica r
+    takes rows [r*B, (r+1)*B) of each global batch, short or empty on the last one."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd.data import W2VDummyDataset
+    sizes = []
+    for r in range(2):
+        ds = W2VDummyDataset(4, length=16, device="cpu", rank=r, world=2, seed=1, drop_remainder=False)
+        it = iter(ds)
+        sizes.append([int(next(it).shape[0]) for _ in range(8)])
+    assert sizes[0] == [4, 4, 4, 4, 4, 4, 2, 4] and sizes[1] == [4, 4, 4, 4, 4, 4, 0, 4]
+    a = W2VDummyDataset(4, length=16, device="cpu", rank=0, world=2, seed=1, drop_remainder=False)
+    b = W2VDummyDataset(4, length=16, device="cpu", rank=1, world=2, seed=1, drop_remainder=False)
+    one = W2VDummyDataset(8, length=16, device="cpu", seed=1, drop_remainder=False)
+    import torch
+    assert torch.equal(torch.cat([next(iter(a)), next(iter(b))]), next(iter(one)))
+

@@ -5,6 +5,7 @@ backward expressed as C-ABI calls.  A model class supplies ``arena``, ``precisio
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -144,6 +145,8 @@ class Arena:
                 v.zero_()
 
 
+
+
 class KernelBlocks:
     # ---- weight-gradient stream ------------------------------------------------------------
     # dW = xᵀ·dy and db = colsum(dy) feed nothing until the optimizer (or the all-reduce), so they run
@@ -249,9 +252,26 @@ class KernelBlocks:
         t = self.ws.get(name)
         dtype = dtype or self.dtype
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            # diagnostics, read when a buffer is created: TMI_WS_GUARD=<elements> puts a guard zone behind every workspace
+            # buffer (check_workspace_guards), TMI_WS_POISON=1|<names> fills the torch.empty ones with NaN
+            guard, poison = int(os.environ.get("TMI_WS_GUARD", "0")), os.environ.get("TMI_WS_POISON", "")
+            if guard:
+                n = int(np.prod(shape))
+                flat = (torch.zeros if zero else torch.empty)(n + guard, dtype=dtype, device=self.device)
+                flat[n:] = 77
+                self.__dict__.setdefault("_guards", {})[(id(self.ws), name)] = (name, flat[n:])
+                t = flat[:n].view(shape)
+            else:
+                t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            if poison and not zero and t.is_floating_point() and (poison == "1" or name in poison.split(",")):
+                t.fill_(float("nan"))  # a workspace buffer read before it is written shows up as NaN
             self.ws[name] = t
         return t
+
+    def check_workspace_guards(self):
+        """Names of workspace buffers whose guard zone (TMI_WS_GUARD=<elements>) was written: a kernel ran past their end."""
+        torch.cuda.synchronize()
+        return [name for name, tail in self.__dict__.get("_guards", {}).values() if not bool((tail == 77).all())]
 
     def _dense_fwd(self, x2d, wname, out2d, n_off=0, n_cols=None, **epi):
         """out = x @ W[:, n_off:n_off+n_cols] (+bias ...).  W is the Keras [in, out] kernel."""

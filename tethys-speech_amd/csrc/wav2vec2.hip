@@ -822,8 +822,13 @@ extern "C" int64_t tmi_fir_chunks(int64_t T) {
   if (n > 64) n = 64;
   return n < 1 ? 1 : n;
 }
+extern "C" int64_t tmi_groupnorm_chunks(int64_t T);
 extern "C" int64_t tmi_fir_gn_workspace_floats(int64_t B, int64_t T, int64_t C) {
-  return B * tmi_fir_chunks(T) * 12 * C;  // per-workgroup partials of dW (10 x C), dgamma, dbeta
+  // per-workgroup partials of dW (10 x C), dgamma, dbeta.  The backward apply pass that writes them runs on
+  // tmi_groupnorm_chunks(T) chunks per sample (see tmi_fir_groupnorm_gelu_bwd), which exceeds tmi_fir_chunks(T) for short
+  // clips (T < ~3200): size for the larger of the two
+  const int64_t a = tmi_fir_chunks(T), b = tmi_groupnorm_chunks(T);
+  return B * (a > b ? a : b) * 12 * C;
 }
 
 extern "C" int tmi_fir_groupnorm_gelu_fwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,

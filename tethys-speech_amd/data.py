@@ -71,14 +71,13 @@ class W2VDummyDataset:
 
     def __init__(self, batch_size, length=32000, device="cuda:0", rank=0, world=1, seed=1234, num_samples=50,
                  drop_remainder=True):
-        """``drop_remainder=False`` (single replica only) is speech_jobs/whisper_single.py:1111's
-        ``dataset.batch(batch_size).repeat()``: the last batch of a pass is short."""
+        """``drop_remainder=False`` is speech_jobs/whisper_single.py:1111's / stable_jobs/wav2vec2_dist.py:1111's
+        ``dataset.batch(global_batch).repeat()``: the last global batch of a pass is short, and a replica's slice
+        [r*B, (r+1)*B) of it may be short or empty."""
         pool = np.random.default_rng(seed).standard_normal((num_samples, length)).astype(np.float32)
         self.audio = torch.from_numpy(pool).to(device)
         self.batch_size, self.rank, self.world = batch_size, rank, world
         self.global_batch = batch_size * world
-        if not drop_remainder and world != 1:
-            raise ValueError("the keep-remainder form is the single-device job's")
         self.n = num_samples // self.global_batch * self.global_batch if drop_remainder else num_samples
         if self.n == 0:
             raise ValueError("global batch larger than the 50-clip pool")
@@ -90,6 +89,6 @@ class W2VDummyDataset:
     def __next__(self):
         if self._pos >= self.n:
             self._pos = 0
-        s = self._pos + self.rank * self.batch_size
+        s = min(self._pos + self.rank * self.batch_size, self.n)
         self._pos += self.global_batch
         return self.audio[s:min(s + self.batch_size, self.n)]

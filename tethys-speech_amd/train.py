@@ -307,9 +307,12 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
 def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_epochs=1, learning_rate=3e-5, *,
                    batch_size=1, num_batches=5, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print,
                    seed=1234, clip_samples=32000, model_overrides=None, dropout=None, resume_from=None,
-                   loss_fetch_depth=2):
+                   loss_fetch_depth=2, epoch_label="Epoch", init_batches=0, checkpoint_stem=None):
     """V:1263-1376: model + Adam(3e-5, eps 1e-8, clipnorm 1), 50 x 2 s dummy clips, per-step log
-    line, checkpoint every 50 steps and at the end."""
+    line, checkpoint every 50 steps and at the end.  speech_jobs/wav2vec2_single.py ("U:") is this loop on one
+    replica (U:1118-1175 is V:1186-1260 without the strategy) with ``epoch_label`` "에포크" (U:1240),
+    ``init_batches`` 1 (the first batch is consumed by the weight-building call, U:1188-1196) and checkpoints
+    named model_step_N / model_epoch_N (U:1272-1275)."""
     import numpy as np
     from .data import W2VDummyDataset
     from .wav2vec2 import create_full_model, sample_negative_indices
@@ -328,6 +331,9 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
     it = iter(ds)
     step, losses = 0, []
     fetch = LossFetcher(device, depth=loss_fetch_depth)
+    for _ in range(init_batches):
+        next(it)
+    stem = checkpoint_stem or f"wav2vec2_{model_type}"
 
     def emit(final):
         for lv, (i, t0) in final:
@@ -340,7 +346,7 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
     start_time = time.time()
     for epoch in range(num_epochs):
-        log(f"Epoch {epoch + 1}/{num_epochs}")
+        log(f"{epoch_label} {epoch + 1}/{num_epochs}")
         for _ in range(num_batches):
             audio = next(it)
             model._prepare(audio.shape[0], audio.shape[1])
@@ -354,12 +360,12 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
                 emit(fetch.drain())
                 os.makedirs(checkpoint_dir, exist_ok=True)
-                save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_step_{step}.pt"),
+                save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"{stem}_step_{step}.pt"),
                                 dataset=ds, step=step)
         emit(fetch.drain())
         if checkpoint_dir and strategy.rank == 0:
             os.makedirs(checkpoint_dir, exist_ok=True)
-            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"wav2vec2_{model_type}_epoch_{epoch + 1}.pt"),
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"{stem}_epoch_{epoch + 1}.pt"),
                             dataset=ds, step=step)
     model.losses = losses
     return model
@@ -424,3 +430,76 @@ def train_wav2vec2_single(model_type="pretraining", num_epochs=1, learning_rate=
             save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"model_epoch_{epoch + 1}.pt"), dataset=ds, step=step)
     model.losses = losses
     return model
+
+
+# ---------------------------------------------------------------------------------------
+# stable_jobs/wav2vec2_dist.py ("T:"): the S: model and step under MultiWorkerMirroredStrategy.  (stable_jobs/whisper_dist.py
+# is byte-identical to speech_jobs/whisper_dist.py.)
+# ---------------------------------------------------------------------------------------
+def stable_wav2vec2_train_step(strategy, model, audio, neg_indices_t, optimizer):
+    """T:1143-1190.  Per replica: forward, loss = contrastive + 0.1 * (-perplexity) as the mean over the LOCAL rows,
+    gradients; ``apply_gradients`` under the strategy all-reduces them with SUM (no 1/N, nothing clipped), Adam; returns
+    strategy.reduce(SUM, loss) (T:1190).  A replica whose slice of a short final batch is empty sends zeros through the
+    same collectives."""
+    model.neg_per_time = True
+    if audio.shape[0] > 0:
+        loss = model.forward_backward(audio, neg_indices_t, num_replicas=1)
+    else:
+        model.arena.g.zero_()
+        loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+    strategy.all_reduce_gradients(model.arena.g)
+    optimizer.apply_gradients(model, None, zero_grad=True)
+    model._pack_pos()
+    return strategy.reduce_sum(loss.clone())
+
+
+def train_wav2vec2_stable(strategy, model_type="pretraining", num_epochs=1, learning_rate=3e-5, *, batch_size=1,
+                          num_batches=40, precision="bf16", device="cuda:0", checkpoint_dir=None, log=print, seed=1234,
+                          clip_samples=80000, model_overrides=None, dropout=None, model_size="base", loss_fetch_depth=2):
+    """T:1193-1268: Wav2Vec2-base + Adam(3e-5) (Keras default epsilon, no clipnorm: T:1200), 50 x 5 s dummy clips batched
+    by the GLOBAL batch without drop_remainder (T:1094-1111, T:1226), per-step log line, checkpoint at the end of the epoch."""
+    import numpy as np
+    from .data import W2VDummyDataset
+    from .wav2vec2 import create_full_model, sample_negative_indices_roll
+    model = create_full_model(model_type, model_size, device=device, precision=precision, seed=seed,
+                              **(model_overrides or {}))
+    strategy.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    if dropout is None:
+        dropout = precision == "bf16"
+    if dropout:
+        c = model.config
+        model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=seed * 1000003 + strategy.rank, act_p=c.activation_dropout)
+    optimizer = Adam(learning_rate=learning_rate)  # Keras default epsilon 1e-7
+    ds = W2VDummyDataset(batch_size, length=clip_samples, device=device, rank=strategy.rank, world=strategy.world, seed=seed,
+                         drop_remainder=False)
+    rng = np.random.default_rng(42)  # the reference asks tf.random.shuffle for seed 42 (T:799)
+    it = iter(ds)
+    step, losses = 0, []
+    start_time = time.time()
+    fetch = LossFetcher(device, depth=loss_fetch_depth)
+
+    def emit(final):
+        for lv, (i, t0) in final:
+            losses.append(lv)
+            log(_step_line(i, lv, start_time, t0, time.time()))
+    for epoch in range(num_epochs):
+        log(f"Epoch {epoch + 1}/{num_epochs}")
+        for _ in range(num_batches):
+            audio = next(it)
+            if audio.shape[0] > 0 or model._ws_key is None:  # (an empty slice runs no kernels; T only depends on the clip length)
+                model._prepare(max(1, audio.shape[0]), clip_samples)
+            # one permutation per replica per step, in rank order (every rank advances the same stream)
+            draws = [sample_negative_indices_roll(rng, model.T, model.config.num_negatives) for _ in range(strategy.world)]
+            neg = torch.from_numpy(draws[strategy.rank]).to(device)
+            step_start = time.time()
+            loss = stable_wav2vec2_train_step(strategy, model, audio, neg, optimizer)
+            emit(fetch.push(loss, (step, step_start)))
+            step += 1
+        emit(fetch.drain())
+        if checkpoint_dir and strategy.rank == 0:
+            os.makedirs(checkpoint_dir, exist_ok=True)
+            save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"model_epoch_{epoch + 1}.pt"), dataset=ds, step=step)
+    model.losses = losses
+    return model
+
