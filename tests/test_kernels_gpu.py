@@ -139,8 +139,12 @@ def test_gemm_kbatch_splitk(dev):
 # k-strided-A form with split-K through workspace slabs and a K tail (weight gradients, K >= 4096),
 # slab split-K on the 128x128 kernel (>= 64 K-tiles), and the 4-stage 64x64 ring (<= 256 tiles, K >= 1536).
 @pytest.mark.parametrize("M,N,K,b_kn", [(2304, 1544, 1536, False), (4352, 768, 704, False), (2304, 1544, 1600, True),
-                                        (4100, 776, 3008, True)])  # (>= 200 128x128 tiles: not the small-problem path)
+                                        (4100, 776, 3008, True),  # ^ 192-row tiles (fewer CU-rounds than 256-row ones)
+                                        (12000, 768, 768, False), (12000, 768, 3072, True),  # the step's N = 768 shapes (192)
+                                        (8192, 2048, 1024, False), (2048, 6144, 1536, True)])  # 256-row tiles
 def test_gemm_eight_phase_paths(dev, M, N, K, b_kn):
+    """(>= 200 128x128 tiles: not the small-problem path.)  The library picks 192- or 256-row tiles by CU-rounds of work
+    (gemm_fast.hip launch_fast); both variants and a ragged last row tile (12000 = 62 * 192 + 96) are covered."""
     ops = _ops()
     bf = torch.bfloat16
     A = rnd((M, K), bf, dev, 11)

@@ -753,15 +753,23 @@ __device__ __forceinline__ void p8_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename TC, bool A_KS, bool B_KS>
+// BM = 256, or 192: the same loop on a 192 x 256 tile - wave rows of 96 = A^0 (64 rows) + A^1 (32 rows, one MFMA row block:
+// the Q11 / Q10 phases issue 4 MFMAs instead of 8, A^1 is an 8 KiB half-tile staged with ONE LDS-DMA per lane, so the
+// counted waits are vmcnt(7) / vmcnt(5)).  For outputs whose 256-row tiling leaves CUs idle or a round mostly empty
+// (M = 12000, N = 768: 141 tiles on 256 CUs -> 189 tiles of 3/4 the work).  k-contiguous A only.
+template <typename TC, bool A_KS, bool B_KS, int BM = 256>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
+  static_assert(BM == 256 || (BM == 192 && !A_KS), "192-row tiles: k-contiguous A only");
+  constexpr int WR = BM / 2;          // rows per wave row
+  constexpr int NMI = WR / 32;        // 32-row accumulator blocks per wave: 4 or 3
+  constexpr int MI1 = NMI - 2;        // row blocks of the A^1 half: 2 or 1
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB]
   const tmi_gemm_desc& d = P.d;
   const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
   const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
   const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
   if (tm >= P.tiles_m || tn >= P.tiles_n) return;
-  const int64_t m0 = (int64_t)tm * 256, n0 = (int64_t)tn * 256;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * 256;
   const int64_t bz = blockIdx.z;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -796,9 +804,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       if constexpr (!A_KS) {
-        int64_t gr = m0 + (ir >> 6) * 128 + 64 * a + (ir & 63);
-        gr = gr < d.M ? gr : d.M - 1;
-        offA[a][i] = (unsigned)((gr * d.a_sm + c * 8) * 2);
+        int64_t gr = m0 + (ir >> 6) * WR + 64 * a + (ir & 63);
+        if (BM == 192 && a == 1) {  // A^1 is [2 wave rows][32 rows]: one load per lane, image row 8 * wave + lane / 8
+          const int ir1 = 8 * wave + (lane >> 3);
+          gr = m0 + (ir1 >> 5) * WR + 64 + (ir1 & 31);
+          gr = gr < d.M ? gr : d.M - 1;
+          offA[a][i] = (unsigned)((gr * d.a_sm + ((lane & 7) ^ ((ir1 >> 1) & 7)) * 8) * 2);
+        } else {
+          gr = gr < d.M ? gr : d.M - 1;
+          offA[a][i] = (unsigned)((gr * d.a_sm + c * 8) * 2);
+        }
       } else {
         int64_t gm = m0 + ((8 * cl) >> 6) * 128 + 64 * a + ((8 * cl) & 63);
         gm = gm + 8 <= P.a_cols_rd ? gm : P.a_cols_rd - 8;
@@ -829,6 +844,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
         if (krs[1] >= klast) o1 -= (unsigned)((krs[1] - (klast - 1)) * sk2);
       }
     }
+    if (BM == 192 && kind == 1) {
+      glds16_so(src, o0, smem + buf * P8_BUF + kind * P8_HALF + wave * 1024);
+      return;
+    }
     glds16_so(src, o0, dst);
     glds16_so(src, o1, dst + 1024);
   };
@@ -838,11 +857,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   int xo[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) xo[kk] = r * 128 + (((2 * kk + h) ^ ((r >> 1) & 7)) << 4);
-  const int arow = wr * 64 * 128, brow = wc * 32 * 128;
+  const int arow = wr * 64 * 128, arow1 = wr * (MI1 * 32) * 128, brow = wc * 32 * 128;
 
-  f32x16 acc[4][2];
+  f32x16 acc[NMI][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NMI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -869,11 +888,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
         }
       }
     } else {
-      const char* img = smem + bufoff + a * P8_HALF + arow;
+      const char* img = smem + bufoff + a * P8_HALF + (a == 0 ? arow : arow1);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 2; ++mi) {
+        if (a == 1 && mi >= MI1) break;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = *reinterpret_cast<const bf16x8*>(img + mi * 4096 + xo[kk]);
+      }
     }
   };
   auto readB = [&](int bufoff, int b, bf16x8 (&br)[4]) {
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 #define P8_MMA(A_, B_, BR_)                                                                               \
   do {                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)     \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int mi = 0; mi < ((A_) == 0 ? 2 : MI1); ++mi) \
         acc[2 * (A_) + mi][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[mi][kk], BR_[kk], acc[2 * (A_) + mi][B_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
@@ -921,7 +942,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 
       readB(ownoff, 1, b1);
       stage(oth, 1, t + 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       p8_barrier();
       P8_MMA(0, 1, b1);
       p8_barrier();
@@ -933,7 +955,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
       p8_barrier();
 
       stage(own, 0, t + 2);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       p8_barrier();
       P8_MMA(1, 0, b0);
       p8_barrier();
@@ -945,13 +968,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 #undef P8_MMA
 
   if (P.dbg & 1) {  // diagnostics: no epilogue (keep the accumulators live)
-    if (acc[0][0][0] + acc[3][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
+    if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
     return;
   }
   char* E = smem + wave * 8192;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-    wide_epilogue<TC>(P, acc[mi][0], acc[mi][1], E, m0 + wr * 128 + mi * 32, n0 + wc * 64, bz, lane, false);
+  for (int mi = 0; mi < NMI; ++mi)
+    wide_epilogue<TC>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1109,11 +1132,11 @@ inline bool p8_eligible(const tmi_gemm_desc& d, bool a_ks, bool b_ks) {
          a_span < 4.0e9 && b_span < 4.0e9;
 }
 
-template <typename TC, bool A_KS, bool B_KS>
+template <typename TC, bool A_KS, bool B_KS, int BM = 256>
 int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   FastParams P;
   P.d = d;
-  P.tiles_m = (int)((d.M + 255) / 256);
+  P.tiles_m = (int)((d.M + BM - 1) / BM);
   P.tiles_n = (int)((d.N + 255) / 256);
   P.ktiles = (int)((d.K + 63) / 64);
   P.a_cols_rd = rup8(d.M);
@@ -1127,7 +1150,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   P.drop_thr = tmi_drop_thr(d.dropout_p);
   P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
   P.drop_scale = tmi_keep_scale(P.drop_thr);
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS, BM>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
   if (attr != hipSuccess) {
     tmi_set_error("tmi_gemm(p8): cannot raise the dynamic LDS limit");
@@ -1171,9 +1194,9 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
   if (splitk > 1) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
-    hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, Q);
+    hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), grid, dim3(512), 2 * P8_BUF, stream, Q);
   });
-  hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS>), grid, dim3(512), 2 * P8_BUF, stream, P);
+  hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), grid, dim3(512), 2 * P8_BUF, stream, P);
   return tmi_check_launch("tmi_gemm(p8)");
 }
 
@@ -1190,6 +1213,9 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   bool big = d.out_dtype == TMI_BF16 && d.M >= 2048 && d.N >= 512 && (d.K * d.kbatch >= 1536 || round_eff >= 0.8);
   if constexpr (!A_KS || B_KS) {  // (k-strided A with k-contiguous B is not instantiated)
     if (force == 10 && p8_eligible(d, A_KS, B_KS) && d.splitk <= 1) return launch_p8<TC, A_KS, B_KS>(d, stream);
+  }
+  if constexpr (!A_KS) {
+    if (force == 14 && p8_eligible(d, false, B_KS) && d.splitk <= 1) return launch_p8<TC, false, B_KS, 192>(d, stream);
   }
   // too few 128x128 tiles to occupy the chip (and not a split-K weight gradient): 64x64 tiles
   const int64_t mid_tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nbatch;
@@ -1234,8 +1260,15 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256 &&
-        (d.K >= 1024 || (!B_KS && light_epi)))
+        (d.K >= 1024 || (!B_KS && light_epi))) {
+      // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
+      static const int no192 = [] { const char* e = getenv("TMI_GEMM_NO_P8_192"); return e ? atoi(e) : 0; }();
+      const int64_t tn = (d.N + 255) / 256;
+      const int64_t t256 = ((d.M + 255) / 256) * tn * d.nbatch, t192 = ((d.M + 191) / 192) * tn * d.nbatch;
+      const int64_t c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
+      if (!no192 && c192 < c256) return launch_p8<TC, false, B_KS, 192>(d, stream);
       return launch_p8<TC, false, B_KS>(d, stream);
+    }
   }
   return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
 }
