@@ -220,3 +220,64 @@ def test_two_rank_stable_wav2vec2_step_matches_oracle(dev):
     ref, _ = TW.V.train_steps_stable(ocfg, params, pool, 2, 2, 4, seed=42, lr=1e-3)
     assert max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(l0, ref)) <= 2e-4, (l0, ref)
 
+
+# ---- speech_jobs/wav2vec2_dist.py ("V:") on two replicas: loss / N, local global-norm clip before the exchange,
+# gradient SUM, per-variable clipnorm after it, Adam eps 1e-8 - against oracle.train_steps(n_replicas=2) in fp64
+def _v_worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    TW = _stable_setup()
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=64 * 1024)
+    model, ocfg, _ = TW.build("fp32", dev)
+    strat.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    opt = optim.Adam(learning_rate=1e-3, epsilon=1e-8)
+    pool = TW.V.create_dummy_pool(seed=3, num_samples=8, length=400)
+    T = TW.V.feature_lengths(ocfg, 400)[-1]
+    rng = np.random.default_rng(77)
+    it = TW.V.batches(pool, 4)
+    losses = []
+    for _ in range(4):
+        a = next(it)
+        neg = TW.V.sample_negative_indices(rng, 4, T, ocfg.num_negatives)
+        sl = slice(2 * rank, 2 * rank + 2)
+        out = train.wav2vec2_train_step(strat, model, torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev),
+                                        torch.from_numpy(np.ascontiguousarray(neg[sl])).to(dev), opt)
+        losses.append(float(out.item()))
+    torch.cuda.synchronize()
+    q.put((rank, model.arena.p.cpu().numpy(), losses))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_wav2vec2_step_matches_oracle(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_v_worker, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, p0, l0), (_, p1, l1) = res
+    assert np.array_equal(p0, p1) and l0 == l1
+    TW = _stable_setup()
+    _, ocfg, params = TW.build("fp32", dev)
+    pool = TW.V.create_dummy_pool(seed=3, num_samples=8, length=400)
+    ref, _ = TW.V.train_steps(ocfg, params, pool, 2, 4, seed=77, n_replicas=2, lr=1e-3)  # (updates ``params`` in place)
+    assert max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(l0, ref)) <= 2e-4, (l0, ref)
+    import tethys_speech_amd  # noqa: F401
+    model, _, _ = TW.build("fp32", dev)
+    model.arena.p.copy_(torch.from_numpy(p0).to(dev))
+    worst = 0.0
+    for k, v in model.arena.ref_views(model.arena.p).items():
+        r = params[k]
+        worst = max(worst, float((v.double().cpu() - r).abs().max() / max(float(r.abs().max()), 1e-3)))
+    # Adam divides by sqrt(v): a parameter whose true gradient is ~0 (k_proj.bias, project_q beta) moves by ~lr either way
+    assert worst <= 4 * 4 * 1e-3, worst
+
