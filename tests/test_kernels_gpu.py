@@ -286,7 +286,10 @@ def _attn_ref(q, k, v, mask_mode, keep=None, keep_scale=1.0):
 @pytest.mark.parametrize("B,H,Tq,Tk,mask,drop", [(2, 3, 100, 100, 1, 0.0), (1, 2, 200, 333, 0, 0.0), (2, 2, 100, 1500, 0, 0.0),
                                                  (1, 1, 31, 31, 1, 0.0), (1, 12, 1500, 1500, 0, 0.0),
                                                  (2, 3, 100, 100, 1, 0.1), (1, 2, 200, 333, 0, 0.1), (2, 2, 100, 1500, 0, 0.25),
-                                                 (1, 4, 1500, 1500, 0, 0.1)])
+                                                 (1, 4, 1500, 1500, 0, 0.1),
+                                                 # key-split path (one query tile, >= 8 key tiles, workspace given): 3 ranges
+                                                 # of 3 tiles / 4 ranges with a ragged last tile / the cross-attention shape
+                                                 (2, 2, 128, 520, 0, 0.0), (1, 3, 37, 1000, 0, 0.1), (8, 12, 100, 1500, 0, 0.1)])
 def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     ops = _ops()
     D = H * 64

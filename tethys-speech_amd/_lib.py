@@ -51,6 +51,7 @@ class AttnDesc(C.Structure):
         ("score_scale", c_f32),
         ("dropout_p", c_f32),
         ("dropout_seed", C.c_uint64),
+        ("workspace", c_vp), ("workspace_bytes", c_i64),
     ]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "tmi_gelu_bwd_batched": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_softmax_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_softmax_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "tmi_attn_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "tmi_attn_fwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "tmi_attn_bwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "tmi_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
@@ -109,7 +111,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 _lib = None
 
 

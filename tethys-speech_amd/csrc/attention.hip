@@ -188,6 +188,66 @@ __device__ __forceinline__ void store_owner(const f32x16 (&y)[2], bf16_t* base, 
 }
 
 
+// the same owner-on-lane tile as fp32 into one row of 64 floats (key-split partials)
+__device__ __forceinline__ void store_owner_f32(const f32x16 (&y)[2], float* row, int h) {
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = y[blk][4 * g + i];
+      *reinterpret_cast<f32x4*>(row + 32 * blk + 8 * g + 4 * h) = v;
+    }
+  }
+}
+
+// Fold of the key-split partials.  One thread per (row, 4 columns): rows = B*H*Tq.
+//   forward: m = max_s m_s; w_s = 2^(m_s - m); l = sum_s l_s w_s; o = (sum_s o_s w_s) * out_scale / l; stats = (m, 1/l)
+//   dQ:      dq = (sum_s dq_s) * out_scale
+template <bool FWD>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part, int ks, int64_t BH, int Tq,
+                                                           bf16_t* __restrict__ out, int64_t o_sb, int64_t o_st, int H,
+                                                           float* __restrict__ stats, float out_scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx >> 4;
+  const int ch = (int)(idx & 15);
+  if (row >= BH * Tq) return;
+  const int64_t bh = row / Tq;
+  const int q = (int)(row - bh * Tq);
+  const float* ml = part + BH * ks * (int64_t)Tq * HD;
+  float m = -INFINITY;
+  if constexpr (FWD) {
+    for (int s_ = 0; s_ < ks; ++s_) m = fmaxf(m, ml[((bh * ks + s_) * Tq + q) * 2]);
+  }
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s_ = 0; s_ < ks; ++s_) {
+    const int64_t r = (bh * ks + s_) * Tq + q;
+    float w = 1.f;
+    if constexpr (FWD) {
+      w = ex2(ml[r * 2] - m);
+      l += ml[r * 2 + 1] * w;
+    }
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + r * HD + 4 * ch);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += v[i] * w;
+  }
+  float sc = out_scale;
+  if constexpr (FWD) sc = out_scale / l;
+  const int64_t b = bh / H, head = bh - b * H;
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (bf16_t)(acc[i] * sc);
+  *reinterpret_cast<bf16x4*>(out + b * o_sb + head * HD + (int64_t)q * o_st + 4 * ch) = o;
+  if constexpr (FWD) {
+    if (ch == 0) {
+      stats[row * 2] = m;
+      stats[row * 2 + 1] = 1.0f / l;
+    }
+  }
+}
+
 #define ZERO2(y)                          \
   _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) y[i_][e_] = 0.f
 
@@ -202,6 +262,11 @@ struct AttnP {
   uint32_t drop_thr;
   float keep_scale;
   uint32_t seed_lo, seed_hi;
+  // key split (forward and dQ passes of a short query side against a long key side: cross-attention, Tq <= 128): the
+  // workgroups of one (batch, head) are `ksplit` disjoint key ranges; each leaves its un-normalised partial in `part`
+  // ([B*H][ksplit][Tq][64] fp32, then for the forward [B*H][ksplit][Tq][2] = (m, l)) and a combine kernel folds them.
+  int ksplit;
+  float* part;
 };
 
 // ABL (diagnostics, TMI_ATTN_ABL): 1 = no softmax arithmetic (p = s), 2 = no second product, 3 = no staging after the
@@ -215,7 +280,8 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   const int c = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int ks = P.ksplit, qt = (int)blockIdx.x / ks, sp = (int)blockIdx.x - qt * ks;
+  const int q = qt * 128 + wave * 32 + c;
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
   const bool causal = d.mask_mode == 1;
   const float c2 = P.c2;
@@ -236,9 +302,11 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
-  const int ntiles = (Tk + TROWS - 1) / TROWS;
-  stage_tile(smem, Ks, 0, wave, lane);
-  stage_tile(smem + IMG, Vs, 0, wave, lane);
+  const int ntiles_all = (Tk + TROWS - 1) / TROWS;
+  const int per = (ntiles_all + ks - 1) / ks;
+  const int t0 = sp * per, ntiles = min(ntiles_all, t0 + per);  // this workgroup's key tiles [t0, ntiles) (host: never empty)
+  stage_tile(smem, Ks, t0 * TROWS, wave, lane);
+  stage_tile(smem + IMG, Vs, t0 * TROWS, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -353,11 +421,23 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
     __syncthreads();
     if (ABL != 3) cur ^= 1;
   };
-  const int nfast = causal ? 0 : Tk / TROWS;  // full, unmasked tiles first
-  int tile = 0;
+  const int nfast = causal ? 0 : min(Tk / TROWS, ntiles);  // full, unmasked tiles first
+  int tile = t0;
   for (; tile < nfast; ++tile) body(tile, std::false_type{});
   for (; tile < ntiles; ++tile) body(tile, std::true_type{});
   l += __shfl_xor(l, 32, 64);
+  if (ks > 1) {  // partial of this key range: un-normalised o, (m, l); attn_combine_fwd_kernel finishes
+    if (q < Tq) {
+      const int64_t row = (((int64_t)b * d.H + head) * ks + sp) * Tq + q;
+      store_owner_f32(o, P.part + row * HD, h);
+      if (h == 0) {
+        float* ml = P.part + (int64_t)d.B * d.H * ks * Tq * HD + row * 2;
+        ml[0] = m;
+        ml[1] = l;
+      }
+    }
+    return;
+  }
   const float inv = 1.0f / l;
   bf16_t* ob = reinterpret_cast<bf16_t*>(d.o) + b * d.o_sb + head * HD;
   store_owner(o, ob, d.o_st, q, Tq, h, DROP ? inv * P.keep_scale : inv);
@@ -378,7 +458,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   const int c = lane & 31, h = lane >> 5;
   const int head = blockIdx.y;
   const int64_t b = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + c;
+  const int ks = P.ksplit, qt = (int)blockIdx.x / ks, sp = (int)blockIdx.x - qt * ks;
+  const int q = qt * 128 + wave * 32 + c;
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
   const bool causal = d.mask_mode == 1;
   const float c2 = P.c2;
@@ -427,9 +508,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
-  const int ntiles = (Tk + TROWS - 1) / TROWS;
-  stage_tile(smem, Ks, 0, wave, lane);
-  stage_tile(smem + IMG, Vs, 0, wave, lane);
+  const int ntiles_all = (Tk + TROWS - 1) / TROWS;
+  const int per = (ntiles_all + ks - 1) / ks;
+  const int t0 = sp * per, ntiles = min(ntiles_all, t0 + per);  // this workgroup's key tiles [t0, ntiles)
+  stage_tile(smem, Ks, t0 * TROWS, wave, lane);
+  stage_tile(smem + IMG, Vs, t0 * TROWS, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -479,10 +562,14 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
     __syncthreads();
     cur ^= 1;
   };
-  const int nfast = causal ? 0 : Tk / TROWS;
-  int tile = 0;
+  const int nfast = causal ? 0 : min(Tk / TROWS, ntiles);
+  int tile = t0;
   for (; tile < nfast; ++tile) body(tile, std::false_type{});
   for (; tile < ntiles; ++tile) body(tile, std::true_type{});
+  if (ks > 1) {  // partial dQ of this key range (unscaled); attn_combine_dq_kernel sums and scales
+    if (q < Tq) store_owner_f32(dq, P.part + ((((int64_t)b * d.H + head) * ks + sp) * Tq + q) * HD, h);
+    return;
+  }
   bf16_t* dqb = reinterpret_cast<bf16_t*>(d.dq) + b * d.dq_sb + head * HD;
   store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale * P.sscale);
 }
@@ -671,6 +758,23 @@ void set_dropout(AttnP& P) {
   P.seed_hi = (uint32_t)(P.d.dropout_seed >> 32);
 }
 
+// key split of the forward / dQ passes: a single query tile against >= 8 key tiles with no causal mask, when the caller
+// gave a workspace (tmi_attn_workspace_bytes).  2..4 ranges, never an empty one.
+int pick_ksplit(const tmi_attn_desc& d) {
+  static const int off = [] { const char* e = getenv("TMI_ATTN_NO_KSPLIT"); return e ? atoi(e) : 0; }();
+  const int64_t ntiles = (d.Tk + TROWS - 1) / TROWS;
+  if (off || d.mask_mode != 0 || d.Tq > 128 || ntiles < 8 || !d.workspace) return 1;
+  int ks = 4;
+  while (ks > 1) {
+    const int64_t per = (ntiles + ks - 1) / ks;
+    if ((ks - 1) * per < ntiles && d.B * d.H * ks <= 1024 &&
+        (int64_t)d.B * d.H * ks * d.Tq * (HD + 2) * 4 <= d.workspace_bytes && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0)
+      break;
+    --ks;
+  }
+  return ks;
+}
+
 int check_common(const tmi_attn_desc& d) {
   if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
       (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && d.dropout_p < 1.f) ||
@@ -681,6 +785,10 @@ int check_common(const tmi_attn_desc& d) {
 }
 
 }  // namespace
+
+extern "C" int64_t tmi_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tq) {
+  return Tq <= 128 ? B * H * 4 * Tq * (HD + 2) * 4 : 0;
+}
 
 extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   if (!dp || !check_common(*dp)) {
@@ -693,7 +801,9 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   P.sscale = dp->score_scale != 0.f ? dp->score_scale : 1.f;
   P.c2 = P.sscale * LOG2E;
   set_dropout(P);
-  dim3 grid((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  P.ksplit = pick_ksplit(*dp);
+  P.part = reinterpret_cast<float*>(dp->workspace);
+  dim3 grid((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   if (P.drop_thr) {
     hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
@@ -704,6 +814,12 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
     else if (abl == 3) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 3>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 4>), grid, dim3(256), 4 * IMG, hs, P);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, hs, P);
+  }
+  if (P.ksplit > 1) {
+    const int64_t rows = dp->B * dp->H * dp->Tq;
+    hipLaunchKernelGGL((attn_combine_kernel<true>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, hs, P.part, P.ksplit,
+                       dp->B * dp->H, (int)dp->Tq, reinterpret_cast<bf16_t*>(dp->o), dp->o_sb, dp->o_st, (int)dp->H, dp->stats,
+                       P.drop_thr ? P.keep_scale : 1.f);
   }
   return tmi_check_launch("tmi_attn_fwd");
 }
@@ -721,13 +837,22 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.c2 = P.sscale * LOG2E;
   set_dropout(P);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 gq((unsigned)((dp->Tq + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  P.ksplit = pick_ksplit(*dp);
+  P.part = reinterpret_cast<float*>(dp->workspace);
+  dim3 gq((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
   if (P.drop_thr)
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
   else
     hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 3>), gq, dim3(256), 4 * IMG, s, P);
+  if (P.ksplit > 1) {
+    const int64_t rows = dp->B * dp->H * dp->Tq;
+    hipLaunchKernelGGL((attn_combine_kernel<false>), dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, P.part, P.ksplit,
+                       dp->B * dp->H, (int)dp->Tq, reinterpret_cast<bf16_t*>(dp->dq), dp->dq_sb, dp->dq_st, (int)dp->H,
+                       (float*)nullptr, P.dq_scale * P.sscale);
+  }
   int rc = tmi_check_launch("tmi_attn_bwd(dq)");
   if (rc) return rc;
+  P.ksplit = 1;
   dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
   if (P.drop_thr)
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);

@@ -224,9 +224,29 @@ def softmax_bwd(p, dp, rows, Tk):
     check(lib().tmi_softmax_bwd(p.data_ptr(), dp.data_ptr(), rows, Tk, stream()), "tmi_softmax_bwd")
 
 
+_ATTN_WS = {}
+
+
+def attn_workspace(device, B, H, Tq):
+    """Key-split scratch of tmi_attn_fwd / tmi_attn_bwd (cross-attention: one query tile against a long key side): one per
+    (device, stream) like the GEMM workspace, grown to the largest (B, H, Tq) seen.  None when the shape never splits."""
+    need = int(lib().tmi_attn_workspace_bytes(B, H, Tq))
+    if need == 0:
+        return None
+    key = (device.type, device.index, stream())
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ATTN_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale=1.0):
     """q,k,v,o: (tensor, element_offset, batch_stride, token_stride)."""
     d = AttnDesc()
+    if mask_mode == 0 and Tq <= 128 and Tk >= 512:
+        ws = attn_workspace(stats.device, B, H, Tq)
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     for name, (t, off, sb, st) in (("q", q), ("k", k), ("v", v), ("o", o)):
         setattr(d, name, t.data_ptr() + off * t.element_size())
         setattr(d, f"{name}_sb", sb)
