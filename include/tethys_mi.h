@@ -182,7 +182,7 @@ typedef struct tmi_attn_desc {
   uint64_t dropout_seed;
   /* Optional fp32 scratch (16-byte aligned, tmi_attn_workspace_bytes(B, H, Tq) bytes; NULL = none).  With it, the forward
    * and dQ passes of a short query side against a long key side (one query tile, >= 8 key tiles of 64, mask_mode 0: the
-   * cross-attention of W:255-301) split the keys over 2-4 workgroups per (batch, head) and fold the partials in a second
+   * cross-attention of W:255-301) split the keys over 2-8 workgroups per (batch, head) and fold the partials in a second
    * launch: the lone 100-row query tile is otherwise one latency chain of 24 key tiles on 96 of 256 CUs. */
   void* workspace;
   int64_t workspace_bytes;

@@ -5,6 +5,5 @@ O=gpurun_out/now
 mkdir -p $O
 D=$O/_t
 TMI_WGRAD_STREAM=0 rocprofv3 --kernel-trace --output-format csv -d $D -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > $O/t.log 2>&1
-python3 tools/step_launches.py $D attn_ > $O/attn_launches.txt
-python3 tools/step_launches.py $D gemm_ > $O/gemm_launches.txt
+python3 tools/step_launches.py $D "" > $O/all_launches.txt
 rm -rf $D
