@@ -133,6 +133,83 @@ __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64
   }
 }
 
+// bf16 rows short enough to be held in registers (ld <= 256 * 8 * XR elements: the 51904-column Whisper logits are 26
+// 16-byte chunks per thread): ONE read of the row, base-2 exponentials (v_exp_f32; the output is bf16), one write.  The
+// generic kernel above reads the row twice and spends most of its time in expf (two calls per element).
+constexpr int XR = 28;
+__global__ __launch_bounds__(256) void xent_rows_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
+                                                             float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / S), t = (int)(row % S);
+  bf16_t* lr = logits + row * ld;
+  const int nch = (int)(ld / 8);
+  if (t >= S - 1) {
+    const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+    for (int ch = threadIdx.x; ch < nch; ch += 256) reinterpret_cast<u32x4*>(lr)[ch] = z;
+    if (threadIdx.x == 0) row_loss[row] = 0.f;
+    return;
+  }
+  const int target = labels[(int64_t)b * S + t + 1];
+  constexpr float L2E = 1.44269504088896340736f;
+  u32x4 raw[XR];
+  float mx = -INFINITY;
+  const int Vi = (int)V;
+  // (columns >= V of the last chunk are padding: they are turned into -inf once, here, so that the passes below are branch-free)
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    const int ch = j * 256 + (int)threadIdx.x;
+    raw[j] = u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};  // bf16 -inf pairs
+    if (ch < nch) {
+      raw[j] = reinterpret_cast<const u32x4*>(lr)[ch];
+      if (ch * 8 + 8 > Vi) {
+        bf16_t* e = reinterpret_cast<bf16_t*>(&raw[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (ch * 8 + i >= Vi) e[i] = (bf16_t)(-INFINITY);
+      }
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
+      float m8 = (float)e[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) m8 = fmaxf(m8, (float)e[i]);
+      mx = fmaxf(mx, m8);
+    }
+  }
+  const float gmx = block_max_256(mx, red);
+  const float nb = -gmx * L2E;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(fmaf((float)e[i], L2E, nb));  // exp2(-inf) = 0 for the padding
+  }
+  const float gsum = block_sum_256(sum, red);
+  const float inv = grad_scale / gsum;
+  if (threadIdx.x == 0) row_loss[row] = gmx + logf(gsum) - (float)lr[target];
+  __syncthreads();  // the target logit is read before anyone overwrites it
+  const int tch = target >> 3, ti = target & 7;
+#pragma unroll
+  for (int j = 0; j < XR; ++j) {
+    const int ch = j * 256 + (int)threadIdx.x;
+    if (ch < nch) {
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] = __builtin_amdgcn_exp2f(fmaf((float)e[i], L2E, nb)) * inv;
+      if (ch == tch) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i == ti) g[i] -= grad_scale;
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (bf16_t)g[i];
+      *reinterpret_cast<bf16x8*>(lr + (int64_t)ch * 8) = o;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                         int64_t n, float scale) {
   __shared__ float red[4];
@@ -238,7 +315,10 @@ extern "C" int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels,
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)(B * S));
-  if (dtype == TMI_BF16)
+  static const int gen = [] { const char* e = getenv("TMI_XENT_GENERIC"); return e ? atoi(e) : 0; }();
+  if (dtype == TMI_BF16 && !gen && ld <= (int64_t)256 * 8 * XR)
+    hipLaunchKernelGGL(xent_rows_bf16_kernel, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V, grad_scale);
+  else if (dtype == TMI_BF16)
     hipLaunchKernelGGL(xent_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V,
                        grad_scale);
   else if (dtype == TMI_F32)
