@@ -457,23 +457,37 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         dres = ws["dres"]
         self._dense_bwd(ws["enc_x"], ws["dpd"], "project_hid.dense.kernel", dres)
 
-        for i in reversed(range(cfg.num_hidden_layers)):
+        # The gradient of the residual stream that a LayerNorm backward leaves in ``dres`` is the dy of the Dense layer below
+        # it (attention out_proj under the FFN LayerNorm, the previous layer's output_dense under the attention LayerNorm):
+        # that layer's bias gradient and - with dropout - its masked copy come out of the LayerNorm kernel
+        # (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dres.  TMI_LN_EMIT=0: separate kernels.
+        emit_on = os.environ.get("TMI_LN_EMIT", "1") != "0"
+        Lh = cfg.num_hidden_layers
+
+        def emit(bias_name, buf, site):
+            return (a.grad(bias_name), ws[buf] if drop else None, site) if emit_on else None
+
+        for i in reversed(range(Lh)):
             p, kk = f"encoder.layers.{i}", f"enc{i}."
             dU, dt_, dctx, dqkv = ws["dU"], ws["dtmp"], ws["dctx"], ws["dqkv"]
+            top = i == Lh - 1  # (the top layer's dres comes from the projection head's dgrad, not from a LayerNorm)
             dy = dres
             if drop:  # the branch sees the masked gradient (same mask, regenerated)
                 dy = ws[f"dyd_f{i & 1}"]
-                self._dropout(dres, dy, SITE_FFN_OUT + i)
+                if top or not emit_on:
+                    self._dropout(dres, dy, SITE_FFN_OUT + i)
             # d u = gelu'(u) * mask/keep * d g: both factors are epilogue terms of the dgrad (elementwise factors commute)
             self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"],
-                            dgrad_epi=self._drop_epi(SITE_FFN_MID + i, p=pa))
+                            dgrad_epi=self._drop_epi(SITE_FFN_MID + i, p=pa), bias_done=emit_on and not top)
             self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_)
-            self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True)
+            self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True,
+                         emit=emit(p + ".attention.out_proj.bias", f"dyd_a{i & 1}", SITE_ATTN_OUT + i))
             dy = dres
             if drop:
                 dy = ws[f"dyd_a{i & 1}"]
-                self._dropout(dres, dy, SITE_ATTN_OUT + i)
-            self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx)
+                if not emit_on:
+                    self._dropout(dres, dy, SITE_ATTN_OUT + i)
+            self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx, bias_done=emit_on)
             qkv = ws[kk + "qkv"]
             self._attn_bwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
                            ws[kk + "ctx"], dctx, (dqkv, 0), (dqkv, H), (dqkv, 2 * H), B, Hh, T, T, 0, score_scale=sscale,
@@ -491,7 +505,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._run_on_side(qkv_weight_grads, dqkv)
             self._guard_write(dt_)
             ops.gemm(dqkv, wq, dt_, R, H, H, 3 * H, 1, 1, H, H, kbatch=3, a_skb=H, b_skb=H * H)
-            self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True)
+            self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True,
+                         emit=emit(f"encoder.layers.{i - 1}.feed_forward.output_dense.bias", f"dyd_f{(i - 1) & 1}",
+                                   SITE_FFN_OUT + i - 1) if i > 0 else None)
 
         # hproj feeds the encoder only (the quantiser branch is non-differentiable)
         if drop:
