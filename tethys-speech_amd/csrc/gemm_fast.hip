@@ -1266,7 +1266,8 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
       const int64_t tn = (d.N + 255) / 256;
       const int64_t t256 = ((d.M + 255) / 256) * tn * d.nbatch, t192 = ((d.M + 191) / 192) * tn * d.nbatch;
       const int64_t c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
-      if (!no192 && c192 < c256) return launch_p8<TC, false, B_KS, 192>(d, stream);
+      // (the 192-row loop does ~10 % less per cycle - two of its four phases issue half the MFMAs - so it has to save more than that)
+      if (!no192 && c192 * 100 <= c256 * 85) return launch_p8<TC, false, B_KS, 192>(d, stream);
       return launch_p8<TC, false, B_KS>(d, stream);
     }
   }
