@@ -300,6 +300,11 @@ def timed_region(one_step, args, strategy, dev, world):
     return float(tmax.item()), float(loss.item()), t_host / args.steps * 1e3
 
 
+def pool_size(global_batch):
+    """Clips in the synthetic pool: the reference's 50 (W:792, V:1130) unless the global batch needs more."""
+    return max(50, 2 * global_batch)
+
+
 def throughput(clip_seconds, per_gpu_batch, world, steps, dt):
     """Whole-job audio-seconds/sec: weak scaling, the per-GPU batch is fixed as N grows."""
     return clip_seconds * per_gpu_batch * world * steps / dt
@@ -356,10 +361,16 @@ def main():
         if args.dropout == "reference":
             model.enable_dropout(model.config.dropout, model.config.attention_dropout, seed=1234 * 1000003 + rank)
         opt = optim.Adam(learning_rate=1e-4)
-        it = iter(create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True))
+        # the reference's pool has 50 clips; weak scaling needs every rank to draw its full batch every step, so the pool grows
+        # with the global batch beyond two of them (N = 4: 64 clips, N = 8: 128); N = 1, 2 keep the 50
+        it = iter(create_dummy_dataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234, drop_remainder=True,
+                                       num_samples=pool_size(args.batch_size * world)))
 
         def one_step():
-            return train.distributed_train_step(strategy, model, next(it), opt)
+            batch = next(it)
+            if batch[0].shape[0] != args.batch_size:
+                raise RuntimeError(f"rank {rank} drew {batch[0].shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
+            return train.distributed_train_step(strategy, model, batch, opt)
         c = model.config
         metric = f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)"
         workload = (f"whisper-{args.model_type}-ref (reference '{args.model_type}': {c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, "
@@ -378,7 +389,8 @@ def main():
             c = model.config
             model.enable_dropout(c.hidden_dropout, c.attention_dropout, seed=1234 * 1000003 + rank, act_p=c.activation_dropout)
         opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
-        it = iter(W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234))
+        it = iter(W2VDummyDataset(args.batch_size, device=dev, rank=rank, world=world, seed=1234,
+                                  num_samples=pool_size(args.batch_size * world)))
         rng = np.random.default_rng(1235)
         # the reference draws its negative indices on the device inside the step; here they are a step input, drawn with
         # its recipe: a ring of pre-drawn index sets already resident in HBM (like the audio batches)
@@ -387,7 +399,10 @@ def main():
 
         def one_step():
             ctr[0] += 1
-            return train.wav2vec2_train_step(strategy, model, next(it), negs[ctr[0] % len(negs)], opt)
+            audio = next(it)
+            if audio.shape[0] != args.batch_size:
+                raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
+            return train.wav2vec2_train_step(strategy, model, audio, negs[ctr[0] % len(negs)], opt)
         metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
         workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
         gf_sample = W2V_GF_PER_SAMPLE.get(size)

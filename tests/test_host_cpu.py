@@ -392,3 +392,23 @@ def test_w2v_dataset_keeps_the_short_batch_across_replicas():
     import torch
     assert torch.equal(torch.cat([next(iter(a)), next(iter(b))]), next(iter(one)))
 
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_bench_pool_gives_every_rank_its_full_batch(world):
+    """bench.py --gpus N is a weak-scaling run: per-GPU batch 8 at every N.  The reference's 50-clip pool cannot feed a
+    global batch of 64, so bench.pool_size grows it; every rank must draw 8 clips on every step, disjoint from its peers'."""
+    import bench
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd.data import W2VDummyDataset, create_dummy_dataset
+    n = bench.pool_size(8 * world)
+    assert n >= 50 and (n == 50 or n >= 2 * 8 * world)
+    its = [iter(create_dummy_dataset(8, n_mels=2, seq_len=4, max_target_length=6, device="cpu", rank=r, world=world, seed=1,
+                                     drop_remainder=True, num_samples=n)) for r in range(world)]
+    w2v = [iter(W2VDummyDataset(8, length=8, device="cpu", rank=r, world=world, seed=1, num_samples=n)) for r in range(world)]
+    for _ in range(5):
+        rows = [next(it)[0] for it in its]
+        assert all(f.shape[0] == 8 for f in rows)
+        flat = torch.cat(rows).reshape(8 * world, -1)
+        assert len({tuple(x.tolist()) for x in flat}) == 8 * world  # distinct clips on every rank
+        assert all(next(it).shape[0] == 8 for it in w2v)
+
