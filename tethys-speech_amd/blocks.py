@@ -147,6 +147,9 @@ class Arena:
 
 
 
+_DEFER_WGRAD = os.environ.get("TMI_DEFER_WGRAD", "0") != "0"
+
+
 class KernelBlocks:
     # ---- weight-gradient stream ------------------------------------------------------------
     # dW = xᵀ·dy and db = colsum(dy) feed nothing until the optimizer (or the all-reduce), so they run
@@ -187,14 +190,19 @@ class KernelBlocks:
         self._ev_i = (self._ev_i + 1) % len(self._ev_ring)
         return ev
 
-    def _run_on_side(self, fn, dy):
+    def _run_on_side(self, fn, dy, defer=False, ready=None):
         """Launch ``fn``'s kernels (readers of the finished buffer ``dy``, writers of gradients only)
-        on the weight-gradient stream, or inline if there is none."""
+        on the weight-gradient stream, or inline if there is none.  ``defer`` (TMI_DEFER_WGRAD=1): do not enqueue yet -
+        ``_flush_deferred`` does, at the point the caller picks (before a kernel the work should run beside)."""
         if self._side is None:
             fn()
             return
-        ready = self._event()
-        ready.record(self._main or torch.cuda.current_stream())  # dy is complete on the main stream here
+        if ready is None:
+            ready = self._event()
+            ready.record(self._main or torch.cuda.current_stream())  # dy is complete on the main stream here
+        if defer and _DEFER_WGRAD:
+            self.__dict__.setdefault("_deferred", []).append((fn, dy, ready))
+            return
         self._side.wait_event(ready)
         prev = ops.set_stream(self._side_handle)
         try:
@@ -205,8 +213,20 @@ class KernelBlocks:
         done.record(self._side)
         self._side_reads[dy.data_ptr()] = done
 
+    def _flush_deferred(self):
+        pend = self.__dict__.get("_deferred")
+        if pend:
+            self._deferred = []
+            for fn, dy, ready in pend:
+                self._run_on_side(fn, dy, ready=ready)
+
     def _guard_write(self, *tensors):
-        if self._side is None or not self._side_reads:
+        if self._side is None:
+            return
+        pend = self.__dict__.get("_deferred")
+        if pend and any(t.data_ptr() == dy.data_ptr() for t in tensors for _, dy, _ in pend):
+            self._flush_deferred()  # a queued-but-not-enqueued reader of this buffer: enqueue it, then wait for it below
+        if not self._side_reads:
             return
         for t in tensors:
             ev = self._side_reads.pop(t.data_ptr(), None)
@@ -215,10 +235,12 @@ class KernelBlocks:
 
     def gradient_streams(self):
         """Streams other than the compute stream on which gradient-producing kernels are queued."""
+        self._flush_deferred()
         return [self._side] if self._side is not None else []
 
     def _join_side(self):
         """Main stream waits for everything queued on the weight-gradient stream."""
+        self._flush_deferred()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_reads.clear()
@@ -286,7 +308,7 @@ class KernelBlocks:
                       bias=bias, **epi)
 
     def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False,
-                   dgrad_epi=None, bias_done=False):
+                   dgrad_epi=None, bias_done=False, defer=False):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
         ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
         before its consumer), so the dgrad goes to the weight-gradient stream too."""
@@ -311,7 +333,7 @@ class KernelBlocks:
             self._guard_write(dx2d)
             self._run_on_side(lambda: (weight_grads(), dgrad()), dy2d)
             return
-        self._run_on_side(weight_grads, dy2d)
+        self._run_on_side(weight_grads, dy2d, defer=defer)
         if dx2d is not None:
             self._guard_write(dx2d)
             dgrad()

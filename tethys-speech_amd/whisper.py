@@ -396,6 +396,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             """Everything stored at or after parameter ``name`` now has its final gradient."""
             if name != next(expected, None):
                 raise RuntimeError(f"backward reported {name} out of the order grad_ready_names() promises")
+            self._flush_deferred()
             lo = a.offsets[name]
             if grad_ready is not None and lo < done[0]:
                 # (a consumer that acts on the range at once must first order itself after the
@@ -640,12 +641,16 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 dy = ws[f"dyd{i & 1}"][:R]
                 if not emit_on:
                     self._dropout(dres, dy, SITE_ENC_FFN + i)
-            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on)
-            self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_)
+            # (TMI_DEFER_WGRAD=1: the two FFN weight gradients are enqueued when the attention backward starts - MFMA-bound work
+            # beside the VALU-bound attention kernels instead of beside the FFN dgrads)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on,
+                            defer=dy is not dres)
+            self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_, defer=True)
             self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True,
                          emit=bias_emit(p + ".self_attn.out_proj.bias"))
             self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on)
             qkv = ws[k + "qkv"]
+            self._flush_deferred()
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0, site=SITE_ENC_ATTN + i)
             self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
