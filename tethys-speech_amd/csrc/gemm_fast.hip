@@ -1259,16 +1259,21 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if constexpr (!A_KS) {
     static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
-    if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256 &&
-        (d.K >= 1024 || (!B_KS && light_epi))) {
+    if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256) {
       // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
       static const int no192 = [] { const char* e = getenv("TMI_GEMM_NO_P8_192"); return e ? atoi(e) : 0; }();
+      static const int short192 = [] { const char* e = getenv("TMI_GEMM_P8_192_SHORTK"); return e ? atoi(e) : 0; }();
       const int64_t tn = (d.N + 255) / 256;
       const int64_t t256 = ((d.M + 255) / 256) * tn * d.nbatch, t192 = ((d.M + 191) / 192) * tn * d.nbatch;
       const int64_t c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
       // (the 192-row loop does ~10 % less per cycle - two of its four phases issue half the MFMAs - so it has to save more than that)
-      if (!no192 && c192 * 100 <= c256 * 85) return launch_p8<TC, false, B_KS, 192>(d, stream);
-      return launch_p8<TC, false, B_KS>(d, stream);
+      const bool win192 = !no192 && c192 * 100 <= c256 * 85;
+      const bool long_k = d.K >= 1024 || (!B_KS && light_epi);
+      // short K with heavy epilogues / k-strided weights (TMI_GEMM_P8_192_SHORTK=1, off): alone and with a plain epilogue the
+      // 192-row tile wins there too (fc1 forward 12000 x 3072 x 768: 100.6 -> 80.3 us), but with the real GELU + aux epilogues
+      // in the step the one-workgroup-per-CU kernel loses to two co-resident 128x128 workgroups: 9.06 -> 9.29 ms/step
+      if (win192 && (long_k || short192)) return launch_p8<TC, false, B_KS, 192>(d, stream);
+      if (long_k) return launch_p8<TC, false, B_KS>(d, stream);
     }
   }
   return big ? launch_cfg<TC, A_KS, B_KS, 5>(d, stream) : launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
