@@ -281,3 +281,58 @@ def test_two_rank_wav2vec2_step_matches_oracle(dev):
     # Adam divides by sqrt(v): a parameter whose true gradient is ~0 (k_proj.bias, project_q beta) moves by ~lr either way
     assert worst <= 4 * 4 * 1e-3, worst
 
+
+# ---- speech_jobs/whisper_dist.py (W:819-848) on two replicas against the fp64 oracle's multi-replica loop, the dataset's
+# own slicing (pool of 6 clips, global batch 4: 4, then a short batch of 2 - rank 0 two rows, rank 1 none)
+def _whisper_oracle_worker(rank, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import test_whisper_step_gpu as TWH
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train
+    from tethys_speech_amd.data import create_dummy_dataset
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=128 * 1024)
+    cfg_kw = TWH.small_cfg()
+    model, _, _ = TWH.build("fp32", cfg_kw, dev)
+    strat.broadcast_parameters(model.arena.p)
+    opt = optim.Adam(1e-3)
+    ds = create_dummy_dataset(2, n_mels=cfg_kw["n_mels"], seq_len=48, max_target_length=12, device=dev, rank=rank, world=2,
+                              seed=21, num_samples=6)
+    feats, labels = TWH.O.create_dummy_pool(seed=21, n_mels=cfg_kw["n_mels"], seq_len=48, max_target_length=12, num_samples=6)
+    ds.features, ds.labels = torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev)  # the oracle's pool
+    it = iter(ds)
+    losses, sizes = [], []
+    for _ in range(4):
+        f, l = next(it)
+        sizes.append(int(f.shape[0]))
+        losses.append(float(train.distributed_train_step(strat, model, (f, l), opt).item()))
+    torch.cuda.synchronize()
+    q.put((rank, model.arena.p.cpu().numpy(), losses, sizes))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_whisper_step_matches_oracle(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_whisper_oracle_worker, args=(r, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p_ in procs:
+        p_.join(60)
+    (_, p0, l0, s0), (_, p1, l1, s1) = res
+    assert np.array_equal(p0, p1) and l0 == l1
+    assert s0 == [2, 2, 2, 2] and s1 == [2, 0, 2, 0]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_whisper_step_gpu as TWH
+    cfg_kw = TWH.small_cfg()
+    _, ocfg, params = TWH.build("fp32", cfg_kw, dev)
+    feats, labels = TWH.O.create_dummy_pool(seed=21, n_mels=cfg_kw["n_mels"], seq_len=48, max_target_length=12, num_samples=6)
+    ref, _ = TWH.O.train_steps(ocfg, params, feats, labels, 2, 4, lr=1e-3, n_replicas=2)
+    assert max(abs(x - y) for x, y in zip(l0, ref)) <= 2e-4, (l0, ref)
+
