@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 export TETHYS_ONE_DEVICE=1 TETHYS_DIST_BACKEND=gloo
 timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node ${1:-4} --master-addr 127.0.0.1 --master-port 29577 \
-  bench.py --gpus ${1:-4} --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse_n4.json 2> gpurun_out/rehearse_n4.log
+  bench.py --gpus ${1:-4} --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse_multi_rank.json 2> gpurun_out/rehearse_multi_rank.log
 echo "rc=$?"
-cat gpurun_out/rehearse_n4.json | cut -c1-700
-grep -E "timed|Error|error" gpurun_out/rehearse_n4.log | head -5
+cat gpurun_out/rehearse_multi_rank.json | cut -c1-700
+grep -E "timed|Error|error" gpurun_out/rehearse_multi_rank.log | head -5
