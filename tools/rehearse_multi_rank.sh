@@ -1,4 +1,4 @@
-# bench.py --gpus ${1:-4} rehearsed on ONE GPU: four ranks share cuda:0, gloo carries the buckets (RCCL cannot put two ranks on a device).
+# bench.py --gpus N (default 4) rehearsed on ONE GPU: the ranks share cuda:0, gloo carries the buckets (RCCL cannot put two ranks on a device).
 # Exercises the launch contract, the weak-scaling data pool, the overlapped bucket exchange, MAX-over-ranks timing and the JSON line;
 # the rate it prints means nothing (host-staged all-reduce of 591 MB per step, four processes time-slicing one device).
 cd $GRAFT_REPO_ROOT
