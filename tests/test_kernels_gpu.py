@@ -230,6 +230,56 @@ def test_layernorm(dev, dtype, rows, Cn):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,Cn,accumulate,drop", [(4100, 768, True, 0.1), (130, 768, False, 0.0), (1000, 1280, True, 0.25),
+                                                     (65, 1024, True, 0.0), (37, 384, False, 0.1)])
+def test_layernorm_bwd_emit(dev, dtype, rows, Cn, accumulate, drop):
+    """tmi_layernorm_bwd_emit: the LayerNorm backward that also emits what the Dense layer below needs of dx - its bias gradient
+    (column sums, accumulated) and, with dropout, the masked copy (W:205 / V:396 / V:431 in backward).  Against the oracle's
+    LayerNorm (autograd) and the host generator's mask; dx / dgamma / dbeta must be those of the plain kernel."""
+    ops = _ops()
+    from oracle import dropout as DO
+    x = rnd((rows, Cn), dtype, dev, 20, 2.0) + 0.5
+    gamma = rnd((Cn,), torch.float32, dev, 21) + 1.0
+    beta = rnd((Cn,), torch.float32, dev, 22)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, 1e-5)
+    xr = x.double().cpu().requires_grad_(True)
+    gr, br = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    dy = rnd((rows, Cn), dtype, dev, 23)
+    O.layer_norm(xr, gr, br, 1e-5).backward(dy.double().cpu())
+    dx0 = rnd((rows, Cn), dtype, dev, 24)
+    dx = dx0.clone()
+    dg = torch.zeros(Cn, dtype=torch.float32, device=dev)
+    db = torch.zeros_like(dg)
+    colsum = rnd((Cn,), torch.float32, dev, 25)  # accumulated into
+    colsum0 = colsum.clone()
+    masked = torch.full_like(x, 7.0) if drop > 0 else None
+    seed = 0xABCDEF12345
+    ops.layernorm_bwd_emit(dy, x, gamma, mean, rstd, dx, dg, db, colsum, masked=masked, dropout_p=drop, dropout_seed=seed,
+                           accumulate_dx=accumulate)
+    torch.cuda.synchronize()
+    ref_dx = xr.grad + (dx0.double().cpu() if accumulate else 0.0)
+    assert rel_err(dx, ref_dx) <= tol(dtype, True)
+    assert rel_err(dg, gr.grad) <= (1e-4 if dtype == torch.float32 else 2e-3)
+    assert rel_err(db, br.grad) <= (1e-4 if dtype == torch.float32 else 2e-3)
+    emitted = dx.double().cpu()  # what the kernel stored (rounded to dtype) is what it masks / sums in fp32 before rounding
+    if drop > 0:
+        keep = torch.from_numpy(DO.keep_flat(seed, rows, Cn, drop))
+        ref_m = ref_dx * keep * DO.keep_scale(drop)
+        assert rel_err(masked, ref_m) <= tol(dtype, True)
+        assert bool(((masked.double().cpu() == 0) | keep).all()) and bool((masked.double().cpu()[~keep] == 0).all())
+        emitted = ref_m
+    else:
+        emitted = ref_dx
+    got = (colsum - colsum0).double().cpu()
+    ref_c = emitted.sum(0)
+    scale = float(emitted.abs().sum(0).max())
+    assert float((got - ref_c).abs().max()) <= (1e-5 if dtype == torch.float32 else 6e-3) * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bias_grad_and_gelu_bwd(dev, dtype):
     ops = _ops()
     rows, N = 1000, 768
