@@ -124,8 +124,10 @@ class Arena:
     def init_keras_defaults(self, seed: int = 1234):
         """Keras default initialisers (SURVEY a-14): glorot-uniform kernels (per reference
         tensor, so each fused q/k/v slice uses fan_in+fan_out of its own [d,d] kernel), zero
-        biases, Embedding U(-0.05, 0.05), LayerNorm gamma=1 / beta=0."""
-        gen = torch.Generator(device="cpu").manual_seed(seed)
+        biases, Embedding U(-0.05, 0.05), LayerNorm gamma=1 / beta=0.  Drawn on the arena's own device (the reference is
+        unseeded; a short job's JCT is mostly model construction: 148 M host-side draws + copies took 2.4 of its 3.5 s)."""
+        gen = torch.Generator(device=self.p.device).manual_seed(seed)
+        dev = self.p.device
         for name, v in self.ref_views(self.p).items():
             shape = tuple(v.shape)
             if name.endswith(".kernel"):
@@ -134,17 +136,15 @@ class Arena:
                 else:
                     fan_in, fan_out = shape
                 lim = math.sqrt(6.0 / (fan_in + fan_out))
-                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * lim)
+                v.copy_((torch.rand(shape, generator=gen, device=dev) * 2 - 1) * lim)
             elif name.endswith(".embeddings"):
-                v.copy_((torch.rand(shape, generator=gen) * 2 - 1) * 0.05)
+                v.copy_((torch.rand(shape, generator=gen, device=dev) * 2 - 1) * 0.05)
             elif name.endswith("codevectors"):
-                v.copy_(torch.randn(shape, generator=gen))  # tf.random.normal (V:571)
+                v.copy_(torch.randn(shape, generator=gen, device=dev))  # tf.random.normal (V:571)
             elif name.endswith(".gamma"):
                 v.fill_(1.0)
             else:
                 v.zero_()
-
-
 
 
 _DEFER_WGRAD = os.environ.get("TMI_DEFER_WGRAD", "0") != "0"
