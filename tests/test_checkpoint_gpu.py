@@ -26,7 +26,12 @@ def test_checkpoint_roundtrip_continues_training(dev, tmp_path):
     run(m1, o1, batches[:2])
     path = str(tmp_path / "ck.pt")
     train.save_checkpoint(m1, o1, path)
+    path_bg = str(tmp_path / "ck_bg.pt")
+    train.save_checkpoint(m1, o1, path_bg, background=True)  # snapshot now, written by a thread while training goes on
     ref = run(m1, o1, batches[2:])
+    train.wait_for_checkpoints()
+    a, b = torch.load(path, map_location="cpu"), torch.load(path_bg, map_location="cpu")
+    assert all(torch.equal(a[k], b[k]) for k in ("p", "m", "v")) and a["iterations"] == b["iterations"] == 2
 
     m2 = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=99, **kw)  # different init
     o2 = optim.Adam(1e-3)

@@ -21,6 +21,7 @@ def test_whisper_training_loop(dev, tmp_path, dropout):
     steps = [l for l in lines if l.startswith("Step ")]
     assert len(steps) == 5 and all("Loss:" in l for l in steps)
     assert (model._drop_p > 0) == (dropout is None)  # default: the reference's rates on the bf16 path
+    train.wait_for_checkpoints()  # (epoch-end checkpoints are written by a background thread)
     assert any(f.endswith(".pt") for f in os.listdir(tmp_path))
     assert all(torch.isfinite(torch.tensor(model.losses)))
 
@@ -40,5 +41,6 @@ def test_wav2vec2_training_loop(dev, tmp_path, dropout):
     steps = [l for l in lines if l.startswith("Step ")]
     assert len(steps) == 4
     assert (model._drop_p > 0) == (dropout is None)
+    train.wait_for_checkpoints()  # (epoch-end checkpoints are written by a background thread)
     assert any(f.endswith(".pt") for f in os.listdir(tmp_path))
     assert all(torch.isfinite(torch.tensor(model.losses)))
