@@ -151,7 +151,8 @@ def cpu_baseline_whisper(model_type, batch, dev, budget_s):
             "loss_check": check}
 
 
-def cpu_baseline_w2v(size, batch, dev, budget_s):
+def cpu_baseline_w2v(size, batch, dev, budget_s, single=False):
+    """``single``: speech_jobs/whisper_single.py's step (S:) - 5 s clips, roll-based negatives, nothing clipped, Adam eps 1e-7."""
     import numpy as np
     import torch
     from oracle import wav2vec2_oracle as V
@@ -159,7 +160,7 @@ def cpu_baseline_w2v(size, batch, dev, budget_s):
     cfg = V.make_config(size)
     params = V.init_params(cfg, seed=1234, dtype=torch.float32)
     params0 = {k: v.clone() for k, v in params.items()}
-    pool = V.create_dummy_pool(seed=1234)
+    pool = V.create_dummy_pool(seed=1234, length=80000) if single else V.create_dummy_pool(seed=1234)
     T = V.feature_lengths(cfg, pool.shape[1])[-1]
     rng = np.random.default_rng(1235)
     it = V.batches(pool, batch)
@@ -170,12 +171,18 @@ def cpu_baseline_w2v(size, batch, dev, budget_s):
         out = []
         for _ in range(n):
             a = next(it)
-            neg = V.sample_negative_indices(rng, batch, T, cfg.num_negatives)
-            used.append((a, neg))
-            loss, g, _ = V.loss_and_grads(params, torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(neg), cfg, 1)
-            g, _ = V.clip_by_global_norm(g, 1.0)
-            g = V.clip_by_norm_each(g, 1.0)
-            V.adam_step(params, g, state, lr=3e-5)
+            if single:
+                neg = V.sample_negative_indices_roll(rng, T, cfg.num_negatives)
+                used.append((a, neg))
+                loss, g, _ = V.loss_and_grads_single(params, torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(neg), cfg)
+                V.adam_step(params, g, state, lr=3e-5, eps=1e-7)
+            else:
+                neg = V.sample_negative_indices(rng, batch, T, cfg.num_negatives)
+                used.append((a, neg))
+                loss, g, _ = V.loss_and_grads(params, torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(neg), cfg, 1)
+                g, _ = V.clip_by_global_norm(g, 1.0)
+                g = V.clip_by_norm_each(g, 1.0)
+                V.adam_step(params, g, state, lr=3e-5)
             out.append(float(loss))
         return out
 
@@ -194,10 +201,14 @@ def cpu_baseline_w2v(size, batch, dev, budget_s):
         m = wav2vec2.create_full_model("pretraining", size, device=dev, precision="fp32", seed=1234)
         m.arena.load_ref(params0)
         m.refresh_shadows()
-        opt = optim.Adam(learning_rate=3e-5, epsilon=1e-8)
+        opt = optim.Adam(learning_rate=3e-5) if single else optim.Adam(learning_rate=3e-5, epsilon=1e-8)
         strat = D.DataParallelStrategy(0, 1)
-        gl = [float(train.wav2vec2_train_step(strat, m, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
-                                              torch.from_numpy(neg).to(dev), opt).item()) for a, neg in used]
+        if single:
+            gl = [float(train.single_train_step(m, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                                torch.from_numpy(neg).to(dev), opt).item()) for a, neg in used]
+        else:
+            gl = [float(train.wav2vec2_train_step(strat, m, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                                  torch.from_numpy(neg).to(dev), opt).item()) for a, neg in used]
         rel = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(gl, cpu_losses))
         check.update({"gpu_fp32_losses": gl, "max_rel_diff": rel, "agree": rel <= 2e-3})
         log(f"loss cross-check CPU oracle fp32 vs GPU fp32 over {len(gl)} steps: max rel = {rel:.2e}")
@@ -205,10 +216,11 @@ def cpu_baseline_w2v(size, batch, dev, budget_s):
         torch.cuda.empty_cache()
     except Exception as e:
         check.update({"error": f"{type(e).__name__}: {e}"})
-    clip = 2.0
+    clip = 5.0 if single else 2.0
     return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
-            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, wav2vec2-{size} pre-training step (V:), "
-                      f"batch {batch}, 2 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
+            "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, wav2vec2-{size} pre-training step "
+                      f"({'S: whisper_single.py' if single else 'V:'}), "
+                      f"batch {batch}, {clip:g} s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
             "cpu_model": cpu_model, "nproc": nproc,
             "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1},
                          {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": 1,
@@ -318,8 +330,9 @@ def main():
     ap.add_argument("--batch_size", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--model_type", default="small")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2"],
-                    help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips)")
+    ap.add_argument("--workload", default="whisper", choices=["whisper", "wav2vec2", "whisper_single"],
+                    help="whisper = BASELINE configs[1] (headline); wav2vec2 = configs[3] model (base, 2 s clips); whisper_single = "
+                         "configs[0] as the file is named: speech_jobs/whisper_single.py's single-device Wav2Vec2-base step, 5 s clips")
     ap.add_argument("--dropout", choices=["off", "reference"], default=None,
                     help="reference (default on bf16): the reference's training-mode Dropout layers (W:29-30, rates 0.1 / 0.1) are "
                          "active, as in its distributed_train_step (training=True), with counter-based masks; "
@@ -408,6 +421,23 @@ def main():
         metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
         workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
         gf_sample = W2V_GF_PER_SAMPLE.get(size)
+        if args.workload == "whisper_single":
+            # speech_jobs/whisper_single.py (S:): the same model, 5 s clips, roll-based negatives, no clipping, Adam eps 1e-7
+            if world != 1:
+                raise SystemExit("whisper_single is the single-device job (S:1303-1324)")
+            clip = 5.0
+            opt = optim.Adam(learning_rate=3e-5)
+            it = iter(W2VDummyDataset(args.batch_size, length=80000, device=dev, seed=1234))
+            model._prepare(args.batch_size, 80000)
+            negs_t = [torch.from_numpy(wav2vec2.sample_negative_indices_roll(rng, model.T, model.config.num_negatives)).to(dev)
+                      for _ in range(16)]
+
+            def one_step():  # noqa: F811
+                ctr[0] += 1
+                return train.single_train_step(model, next(it), negs_t[ctr[0] % len(negs_t)], opt)
+            metric = "audio-seconds/sec/node (whisper_single.py = Wav2Vec2-base single-device step, 5 s clips)"
+            workload = f"speech_jobs/whisper_single.py step (S:): wav2vec2-base, batch {args.batch_size}, 5 s clips [80000]"
+            gf_sample = None
         tag = f"wav2vec2_{size}"
 
     log(f"model ready ({model.arena.n_params} params), warming up {args.warmup} steps")
@@ -439,7 +469,8 @@ def main():
             if args.workload == "whisper":
                 out["cpu_baseline"] = cpu_baseline_whisper(args.model_type, args.batch_size, dev, args.cpu_budget)
             else:
-                out["cpu_baseline"] = cpu_baseline_w2v(size, args.batch_size, dev, args.cpu_budget)
+                out["cpu_baseline"] = cpu_baseline_w2v(size, args.batch_size, dev, args.cpu_budget,
+                                                       single=args.workload == "whisper_single")
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
