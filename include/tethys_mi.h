@@ -186,6 +186,10 @@ typedef struct tmi_attn_desc {
    * launch: the lone 100-row query tile is otherwise one latency chain of 24 key tiles on 96 of 256 CUs. */
   void* workspace;
   int64_t workspace_bytes;
+  /* tmi_attn_bwd only.  0 or 3: both passes; 1: the dQ pass alone (it also fills `delta`); 2: the dK/dV pass alone, after a
+   * dQ pass of the same descriptor has filled `delta`.  Lets a caller put the dK/dV pass of a cross-attention - whose results
+   * nothing on the decoder's backward chain waits for (W:255-301: dK, dV feed the shared k/v projections) - on another stream. */
+  int32_t bwd_passes;
 } tmi_attn_desc;
 int64_t tmi_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tq);
 int tmi_attn_fwd(const tmi_attn_desc* d, void* stream);

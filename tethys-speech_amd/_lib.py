@@ -52,6 +52,7 @@ class AttnDesc(C.Structure):
         ("dropout_p", c_f32),
         ("dropout_seed", C.c_uint64),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
+        ("bwd_passes", c_i32),
     ]
 
 
@@ -111,7 +112,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 _lib = None
 
 

@@ -148,6 +148,7 @@ class Arena:
 
 
 _DEFER_WGRAD = os.environ.get("TMI_DEFER_WGRAD", "0") != "0"
+_DKV_ON_SIDE = os.environ.get("TMI_CROSS_DKV_SIDE", "1") != "0"
 
 
 class KernelBlocks:
@@ -416,7 +417,10 @@ class KernelBlocks:
                      a_off=b * H * Tq * Tk, b_off=b * Tk * vt.stride(0) + vo, c_off=b * Tq * d)
 
     def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask, score_scale=1.0,
-                  q_prescaled=True, site=None):
+                  q_prescaled=True, site=None, dkv_on_side=False):
+        """``dkv_on_side``: the dK/dV pass goes to the weight-gradient stream (cross-attention: nothing on the decoder's
+        backward chain reads dK / dV; the caller joins that stream before it does).  ``dctx2d`` must then be a buffer nothing
+        on the main stream rewrites soon (a ``_guard_write`` on it waits for the pass)."""
         d = self.hidden
         hd = d // H
         scaling = hd ** -0.5
@@ -426,11 +430,22 @@ class KernelBlocks:
         if self.precision == "bf16":
             def m(t, off, T):
                 return (t, off, T * t.stride(0), t.stride(0))
-            ops.attn_bwd(m(qt, qo, Tq), m(kt, ko, Tk), m(vt, vo, Tk), m(ctx2d, 0, Tq), self.ws[key],
-                         m(dctx2d, 0, Tq), m(dqt, dqo, Tq), m(dkt, dko, Tk), m(dvt, dvo, Tk), self.ws["delta"],
-                         B, H, Tq, Tk, mask, dq_scale=scaling if q_prescaled else 1.0, score_scale=score_scale,
-                         dropout_p=self._drop_attn_p if site is not None else 0.0,
-                         dropout_seed=self._site_seed(site) if (site is not None and self._drop_attn_p > 0) else 0)
+            split = dkv_on_side and self._side is not None and _DKV_ON_SIDE
+            # (a pass on another stream reads delta later: its own buffer, not the one every attention backward shares)
+            delta = self._buf(key + ".delta", (B, H, Tq), torch.float32) if split else self.ws["delta"]
+
+            def run(passes):
+                ops.attn_bwd(m(qt, qo, Tq), m(kt, ko, Tk), m(vt, vo, Tk), m(ctx2d, 0, Tq), self.ws[key],
+                             m(dctx2d, 0, Tq), m(dqt, dqo, Tq), m(dkt, dko, Tk), m(dvt, dvo, Tk), delta,
+                             B, H, Tq, Tk, mask, dq_scale=scaling if q_prescaled else 1.0, score_scale=score_scale,
+                             dropout_p=self._drop_attn_p if site is not None else 0.0,
+                             dropout_seed=self._site_seed(site) if (site is not None and self._drop_attn_p > 0) else 0,
+                             passes=passes)
+            if split:
+                run(1)
+                self._run_on_side(lambda: run(2), dctx2d)
+            else:
+                run(0)
             return
         P = self.ws[key]
         dP = self.ws["dP"]

@@ -838,8 +838,14 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.c2 = P.sscale * LOG2E;
   set_dropout(P);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const bool do_dq = dp->bwd_passes != 2, do_dkv = dp->bwd_passes != 1;
+  if (dp->bwd_passes < 0 || dp->bwd_passes > 3) {
+    tmi_set_error("tmi_attn_bwd: bwd_passes must be 0 (both), 1 (dQ), 2 (dK/dV) or 3 (both)");
+    return TMI_ERR_INVALID;
+  }
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
+  if (do_dq) {
   dim3 gq((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
   if (P.drop_thr)
     hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
@@ -853,6 +859,8 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   }
   int rc = tmi_check_launch("tmi_attn_bwd(dq)");
   if (rc) return rc;
+  }
+  if (!do_dkv) return TMI_OK;
   P.ksplit = 1;
   dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
   if (P.drop_thr)

@@ -266,9 +266,11 @@ def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0, drop
 
 
 def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0,
-             dropout_p=0.0, dropout_seed=0):
+             dropout_p=0.0, dropout_seed=0, passes=0):
+    """``passes``: 0 both, 1 the dQ pass (fills ``delta``), 2 the dK/dV pass (needs ``delta`` from pass 1)."""
     d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    d.bwd_passes = passes
     for name, field, (t, off, sb, st) in (("d_o", "do", do), ("dq", "dq", dq), ("dk", "dk", dk), ("dv", "dv", dv)):
         setattr(d, name, t.data_ptr() + off * t.element_size())
         setattr(d, f"{field}_sb", sb)
@@ -277,7 +279,8 @@ def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0
     d.dq_scale = dq_scale
     # algorithmic work as SURVEY 8(d) defines it: fwd + bwd = 3 x forward, i.e. backward = 2 x 4.B.H.Tq.Tk.64
     # (the two passes execute seven products: both recompute S and dP)
-    with _probe("attention", 8.0 * B * H * Tq * Tk * 64):
+    # (3 of the 7 products are the dQ pass, 4 the dK/dV pass)
+    with _probe("attention", 8.0 * B * H * Tq * Tk * 64 * (1.0 if passes in (0, 3) else (3.0 / 7.0 if passes == 1 else 4.0 / 7.0))):
         check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
 
 

@@ -286,6 +286,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         if self.precision == "bf16":
             self._buf("lmh_dx32", (Rd, d), f32)  # split-K accumulator of the LM-head dgrad
         self._buf("dctx", (Rm, d))
+        self._buf("dctxc0", (B * S, d)); self._buf("dctxc1", (B * S, d))  # dO of the cross-attention backward (alternating by layer)
         if self._drop_p > 0.0:
             # masked copies of the residual-stream gradient (dropout mode): two buffers used by alternate layers, so a
             # layer's mask pass does not have to wait for the previous layer's weight gradient, which still reads its copy
@@ -582,12 +583,15 @@ class WhisperForConditionalGeneration(KernelBlocks):
             self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
             self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True,
                          emit=bias_emit(p + ".encoder_attn.out_proj.bias"))
-            # cross attention
-            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctx, bias_done=emit_on)
+            # cross attention: dK / dV feed only the shared k/v projections' backward after the loop, so their pass runs on the
+            # second stream (its dO lives in a buffer of its own: the chain rewrites ws["dctx"] two kernels later)
+            dctxc = ws[f"dctxc{i & 1}"][:Rd]
+            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctxc, bias_done=emit_on)
             dqc = ws["dtmp"][:Rd]
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
-                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctx, (dqc, 0),
-                           (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0, site=SITE_DEC_CROSS + i)
+                           (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctxc, (dqc, 0),
+                           (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0, site=SITE_DEC_CROSS + i,
+                           dkv_on_side=not kv_per_layer)
             if kv_per_layer:
                 # this layer's dk / dv are final: its share of the cross-attention k/v projections' backward (weight
                 # and bias gradient, and d enc_out += dkv_i . Wkv_i^T) goes to the second stream now, under the chain of
@@ -616,8 +620,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
             if kv_per_layer:
                 self._main.wait_event(self._side_reads.pop(dkv.data_ptr()))  # d_enc is complete after layer 0's share
             else:
-                # every layer's dk / dv is in place: one weight gradient, one bias gradient and one dgrad
-                # (K = L*2d) for the cross-attention k/v projections of all layers
+                # every layer's dk / dv is in place (their passes ran on the second stream: join it): one weight gradient, one
+                # bias gradient and one dgrad (K = L*2d) for the cross-attention k/v projections of all layers
+                self._join_side()
                 self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
             ready("decoder.cross_kv.kernel")
         if drop:
