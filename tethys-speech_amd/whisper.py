@@ -625,9 +625,14 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 self._join_side()
                 self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
             ready("decoder.cross_kv.kernel")
-        if drop:
-            self._dropout(dres, dres, SITE_DEC_EMBED)
-        ops.embed_bwd(labels, dres, a.grad("decoder.embed_tokens.embeddings"), B, S, d, cfg.decoder_start_token_id)
+        # the embedding's backward (mask of W:411, scatter of the rows) feeds nothing on the chain: second stream
+        gemb, dres_dec = a.grad("decoder.embed_tokens.embeddings"), dres
+
+        def embed_backward():
+            if drop:
+                ops.dropout(dres_dec, dres_dec, dres_dec.shape[0], dres_dec.shape[1], self._drop_p, self._site_seed(SITE_DEC_EMBED))
+            ops.embed_bwd(labels, dres_dec, gemb, B, S, d, cfg.decoder_start_token_id)
+        self._run_on_side(embed_backward, dres_dec)
         ready("decoder.embed_tokens.embeddings")
 
         # ---- encoder backward
