@@ -293,7 +293,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             for nm in ("dyd_f0", "dyd_f1", "dyd_a0", "dyd_a1"):
                 self._buf(nm, (R, H))
         self._buf("dqkv", (R, 3 * H)); self._buf("dU", (R, ff))
-        self._buf("dph", (R, pd)); self._buf("dpq", (R, pd)); self._buf("dpd", (R, pd))
+        self._buf("dph", (R, pd)); self._buf("dpq", (R, pd)); self._buf("dpd", (R, pd)); self._buf("dpd_q", (R, pd))
         self._buf("dquant", (R, cd))
         self._buf("dfeats", (R, C)); self._buf("dhp", (R, C)); self._buf("dh_last", (R, C))
         if self.precision == "bf16":
@@ -449,9 +449,12 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._dropout(ws["dpq"], ws["dpq"], SITE_PQ)
             self._dropout(ws["dph"], ws["dph"], SITE_PH)
         # project_q branch -> codebook
-        self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd"], "pq_ln", False)
-        self._dense_bwd(ws["quant"], ws["dpd"], "project_q.dense.kernel", ws["dquant"])
-        ops.vq_bwd(ws["code_idx"], ws["dquant"], a.grad("quantizer.codevectors"), R, Gq, Nc, gd)
+        # (the quantiser branch ends in the codebook: its dense backward and the codebook scatter feed nothing on the chain
+        # and run on the second stream, from a buffer of their own - ws["dpd"] is reused by the other head at once)
+        self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd_q"], "pq_ln", False)
+        self._dense_bwd(ws["quant"], ws["dpd_q"], "project_q.dense.kernel", ws["dquant"], dgrad_on_side=True)
+        gcode = a.grad("quantizer.codevectors")
+        self._run_on_side(lambda: ops.vq_bwd(ws["code_idx"], ws["dquant"], gcode, R, Gq, Nc, gd), ws["dquant"])
         # project_hid branch -> encoder output
         self._ln_bwd(ws["dph"], ws["ph_pre"], "project_hid.layer_norm", ws["dpd"], "ph_ln", False)
         dres = ws["dres"]
