@@ -381,6 +381,9 @@ int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, int64_t neg_sb, int64_
  * One segment covering the arena = tf.clip_by_global_norm (V:1243); one segment per variable
  * = Keras clipnorm (V:1274). */
 int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* out, int64_t nseg, void* stream);
+/* The same sums over the chunk table of tmi_adam_step_segments ([nchunks][3] = lo, hi, segment index): equal pieces of work
+ * instead of one workgroup row per segment.  out[nseg] is zeroed first. */
+int tmi_segment_sumsq_chunks(const float* g, const int64_t* chunks, int64_t nchunks, float* out, int64_t nseg, void* stream);
 int tmi_segment_clip(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,
                      void* stream);
 

@@ -173,6 +173,15 @@ def test_segment_clip(dev):
     one = torch.tensor([0, 10000], dtype=torch.int64, device=dev)
     ops.segment_sumsq(g0, one, ss, 1)
     assert abs(float(ss[0]) - float((g0.double() ** 2).sum())) <= 1e-4 * float((g0.double() ** 2).sum())
+    # the chunk-table form (tmi_segment_sumsq_chunks) gives the same per-segment sums
+    big = rnd((300000,), torch.float32, dev, 31, 0.05)
+    offs2 = torch.tensor([0, 104, 40000, 40008, 250000, 300000], dtype=torch.int64, device=dev)
+    chunks = ops.segment_chunks(offs2, device=dev)
+    s1, s2 = torch.empty(5, dtype=torch.float32, device=dev), torch.full((5,), 9.0, dtype=torch.float32, device=dev)
+    ops.segment_sumsq(big, offs2, s1, 5)
+    ops.segment_sumsq_chunks(big, chunks, s2, 5)
+    exact = torch.stack([(big[a:b].double() ** 2).sum() for a, b in zip(offs2[:-1].tolist(), offs2[1:].tolist())])
+    assert rel_err(s2, exact) <= 1e-5 and rel_err(s1, exact) <= 1e-5
 
 
 @pytest.mark.parametrize("clip_global,clip_each", [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0)])

@@ -107,12 +107,13 @@ SIGNATURES = {
     "tmi_grad_unpack": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp]),
     "tmi_contrastive_fwd_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, c_f32, c_vp]),
     "tmi_segment_sumsq": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "tmi_segment_sumsq_chunks": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "tmi_segment_clip": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_f32, c_vp]),
     "tmi_loss_combine": (c_i32, [c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 _lib = None
 
 

@@ -694,6 +694,40 @@ __global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restr
   if (threadIdx.x == 0 && a < b) atomicAdd(out + s, acc);
 }
 
+// The same sums over the chunk table of tmi_adam_step_segments ([nchunks][3] = lo, hi, segment; chunks of <= 8192 elements
+// starting 16-byte aligned): a grid-stride walk over equal pieces of work instead of one (segment x slice) block each - the
+// variables range from 512 to 2.4 M elements, and 16 slices of a bias vector are 16 idle workgroups.
+__global__ __launch_bounds__(256) void segment_sumsq_chunks_kernel(const float* __restrict__ g, const int64_t* __restrict__ chunks,
+                                                                   int64_t nchunks, float* __restrict__ out) {
+  __shared__ float red[4];
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t lo = chunks[3 * c], hi = chunks[3 * c + 1];
+    const int seg = (int)chunks[3 * c + 2];
+    const int64_t nv = ((lo & 3) == 0) ? (hi - lo) / 4 : 0;
+    const f32x4* gv = reinterpret_cast<const f32x4*>(g + lo);
+    float acc = 0.f;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < nv; i += 1024) {
+      const f32x4 v0 = gv[i], v1 = gv[i + 256], v2 = gv[i + 512], v3 = gv[i + 768];
+      acc += v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3];
+      acc += v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3];
+      acc += v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3];
+      acc += v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3];
+    }
+    for (; i < nv; i += 256) {
+      const f32x4 v = gv[i];
+      acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    for (int64_t j = lo + nv * 4 + threadIdx.x; j < hi; j += 256) {
+      const float v = g[j];
+      acc += v * v;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out + seg, acc);
+    __syncthreads();  // red[] is reused by the next chunk
+  }
+}
+
 // g[i] *= clip / max(sqrt(sumsq[seg(i)] ), clip)     (tf.clip_by_norm per segment; one segment = global norm)
 __global__ __launch_bounds__(256) void segment_clip_kernel(float* __restrict__ g, const int64_t* __restrict__ seg_off,
                                                            const float* __restrict__ sumsq, float clip) {
@@ -997,6 +1031,19 @@ extern "C" int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* 
   const unsigned split = nseg == 1 ? 512u : 16u;  // (every block ends with an atomic on out[s])
   hipLaunchKernelGGL(segment_sumsq_kernel, dim3((unsigned)nseg, split), dim3(256), 0, s, g, seg_off, out);
   return tmi_check_launch("tmi_segment_sumsq");
+}
+
+extern "C" int tmi_segment_sumsq_chunks(const float* g, const int64_t* chunks, int64_t nchunks, float* out, int64_t nseg,
+                                        void* stream) {
+  if (!g || !chunks || !out || nchunks <= 0 || nseg <= 0) {
+    tmi_set_error("tmi_segment_sumsq_chunks: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(out, 0, (size_t)nseg * sizeof(float), s) != hipSuccess) return TMI_ERR_LAUNCH;
+  hipLaunchKernelGGL(segment_sumsq_chunks_kernel, dim3((unsigned)(nchunks < 2048 ? nchunks : 2048)), dim3(256), 0, s, g, chunks,
+                     nchunks, out);
+  return tmi_check_launch("tmi_segment_sumsq_chunks");
 }
 
 extern "C" int tmi_segment_clip(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,

@@ -492,6 +492,12 @@ def contrastive_fwd_bwd(S, neg, row_loss, B, T, Nn, temperature, grad_scale, per
                                         grad_scale, stream()), "tmi_contrastive_fwd_bwd")
 
 
+def segment_sumsq_chunks(g, chunks, out, nseg):
+    """Per-variable sums of squares over the chunk table of ``segment_chunks`` (tmi_segment_sumsq_chunks)."""
+    check(lib().tmi_segment_sumsq_chunks(g.data_ptr(), chunks.data_ptr(), chunks.shape[0], out.data_ptr(), nseg, stream()),
+          "tmi_segment_sumsq_chunks")
+
+
 def segment_sumsq(g, seg_off, out, nseg):
     check(lib().tmi_segment_sumsq(g.data_ptr(), seg_off.data_ptr(), out.data_ptr(), nseg, stream()), "tmi_segment_sumsq")
 

@@ -315,7 +315,7 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
         # one replica: both clips are factors of the same raw gradients, so ONE sum-of-squares pass (per variable; the
         # global norm is their sum) feeds an Adam launch that applies c_global * c_variable on the fly
         if audio.shape[0] > 0:
-            ops.segment_sumsq(a.g, model.seg_vars, ws["clip_vars"], model.n_var)
+            ops.segment_sumsq_chunks(a.g, model.seg_chunks, ws["clip_vars"], model.n_var)
             optimizer.apply_gradients_clipped(model, model.seg_chunks, ws["clip_vars"], model.n_var, clip_global=1.0,
                                               clip_each=1.0, zero_grad=True)
         else:
