@@ -300,8 +300,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._buf("delta", (B, cfg.num_attention_heads, self.T), f32)
         else:
             self._buf("dP", (B, cfg.num_attention_heads, self.T, self.T), f32)
-        maxrows = max(1 + t for t in self.lens)
-        self._buf("dupad", (B * maxrows * max(cfg.conv_dim),), **z)
+        for i in range(L):  # conv-layer input gradients with a zero row in front (the k = 3 dgrad's tap at t - 1)
+            if not (i == 0 and self.fir0):
+                self._buf(f"dup{i}", (B, 1 + self.lens[i], cfg.conv_dim[i]), **z)
         nch = max([ops.groupnorm_chunks(t) for t in self.lens] + ([ops.fir_chunks(self.lens[0])] if self.fir0 else []))
         self._buf("gn_part", (B * nch * Gn * 2,), f32)
         self._buf("gn_sums", (B, Gn, 2), f32)
@@ -551,8 +552,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                                            dy_off=dyoff)
                 continue
             u = ws[f"u{i}"]
-            dup = ws["dupad"][:B * (1 + Ti) * c].view(B, 1 + Ti, c)  # row 0 of every batch stays zero
-            dup[:, 0].zero_()
+            dup = ws[f"dup{i}"]  # [B, 1 + Ti, c], row 0 of every batch stays zero (allocated zeroed, never written)
             ops.groupnorm_gelu_bwd(u, u.stride(0), dy, dysb, a.param(pre + ".gamma"), a.param(pre + ".beta"),
                                    ws[f"gn{i}.stats"], dup, dup.stride(0), a.grad(pre + ".gamma"), a.grad(pre + ".beta"),
                                    ws["gn_part"], ws["gn_sums"], B, Ti, c, Gn, dy_off=dyoff, dx_off=c)
