@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0            # HBM3E peak (same guide; ~6.3 TB/s is what str
 GF_PER_SAMPLE_BY_SIZE = {"tiny": 141.3, "small": 449.1, "large": 8320.6}  # SURVEY.md 8(d), 30 s clips
 W2V_GF_PER_SAMPLE = {"base": 83.43}                                        # SURVEY.md 8(d), 2 s clips
 POD_CPU_LIMIT = 5                # sample_tfjobs/whisper-dist.yaml:36
+CPU_TIMED_MIN = 3                # 1 warm-up + >= 3 timed steps per thread setting
 
 
 def log(msg):
@@ -67,7 +68,9 @@ def host_cpu():
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    share = int(os.environ.get("TMI_BENCH_CPU_SHARE", "16"))  # a 1-GPU box's CPU share: more threads only thrash
+    # "all physical cores of one socket" (and 5, the reference pod's limit).  TMI_BENCH_CPU_SHARE
+    # caps it for a box whose cgroup share is smaller than its affinity mask says (unset: no cap)
+    share = int(os.environ.get("TMI_BENCH_CPU_SHARE", "0")) or (per_socket or avail)
     threads = max(1, min(avail, per_socket or avail, share))
     return model, threads, avail
 
@@ -87,9 +90,10 @@ def _time_oracle(run_steps, threads, warm, timed):
 
 
 def cpu_baseline_whisper(model_type, batch, dev, budget_s):
-    """Oracle fp32 on the bench batch (pool seed 1234, batch ``batch``, 30 s clips).  Setting 1: 1 warm-up + as many
-    timed steps as fit ~budget_s (at most 3); setting 2 (5 threads): continues from there for 1 step (no new warm-up:
-    the CPU path compiles nothing).  The GPU fp32 path then runs the same steps from the same initial weights."""
+    """Oracle fp32 on the bench batch (pool seed 1234, batch ``batch``, 30 s clips).  Setting 1 (all physical cores of one
+    socket): 1 warm-up + at least 3 timed steps (more if they fit ~budget_s, at most 6); setting 2 (5 threads): continues
+    from there for 3 timed steps (no new warm-up: the CPU path compiles nothing).  BASELINE.md section 3.4: 1 warm-up +
+    >= 3 timed steps.  The GPU fp32 path then runs the same steps from the same initial weights."""
     import numpy as np
     import torch
     from oracle import whisper_oracle as O  # checker, timed as the CPU baseline only
@@ -117,9 +121,11 @@ def cpu_baseline_whisper(model_type, batch, dev, budget_s):
     warm_s = time.time() - t0
     log(f"cpu baseline warm-up step: {warm_s:.1f} s on {threads} threads ({cpu_model})")
     torch.set_num_threads(threads)
-    n1 = max(1, min(3, int(budget_s / max(warm_s, 1e-3))))
+    n1 = max(CPU_TIMED_MIN, min(6, int(budget_s / max(warm_s, 1e-3))))
     s1, l1 = _time_oracle(run_steps, threads, 0, n1)
-    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, 1)
+    log(f"cpu baseline: {s1:.2f} s/step over {n1} timed steps on {threads} threads")
+    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, CPU_TIMED_MIN)
+    log(f"cpu baseline: {s5:.2f} s/step over {CPU_TIMED_MIN} timed steps on {min(POD_CPU_LIMIT, nproc)} threads")
     cpu_losses = first + l1 + l5
     # the GPU fp32 (parity) path on the same batches from the same initial weights
     import tethys_speech_amd  # noqa: F401
@@ -143,10 +149,12 @@ def cpu_baseline_whisper(model_type, batch, dev, budget_s):
     clip = 30.0
     return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
             "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, batch {batch}, "
-                      f"30 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
+                      f"30 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads "
+                      f"(all physical cores of one socket; {CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
             "cpu_model": cpu_model, "nproc": nproc,
-            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1},
-                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": 1,
+            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1,
+                          "note": "all physical cores of one socket (BASELINE.md 3.3)"},
+                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": CPU_TIMED_MIN,
                           "note": "the reference pod's CPU limit (sample_tfjobs/whisper-dist.yaml:36)"}],
             "loss_check": check}
 
@@ -190,9 +198,9 @@ def cpu_baseline_w2v(size, batch, dev, budget_s, single=False):
     t0 = time.time()
     first = run_steps(1)
     warm_s = time.time() - t0
-    n1 = max(1, min(4, int(budget_s / max(warm_s, 1e-3))))
+    n1 = max(CPU_TIMED_MIN, min(6, int(budget_s / max(warm_s, 1e-3))))
     s1, l1 = _time_oracle(run_steps, threads, 0, n1)
-    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, 1)
+    s5, l5 = _time_oracle(run_steps, min(POD_CPU_LIMIT, nproc), 0, CPU_TIMED_MIN)
     cpu_losses = first + l1 + l5
     import tethys_speech_amd  # noqa: F401
     from tethys_speech_amd import dist as D, optim, train, wav2vec2
@@ -220,10 +228,12 @@ def cpu_baseline_w2v(size, batch, dev, budget_s, single=False):
     return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
             "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, wav2vec2-{size} pre-training step "
                       f"({'S: whisper_single.py' if single else 'V:'}), "
-                      f"batch {batch}, {clip:g} s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads",
+                      f"batch {batch}, {clip:g} s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads "
+                      f"(all physical cores of one socket; {CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
             "cpu_model": cpu_model, "nproc": nproc,
-            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1},
-                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": 1,
+            "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1,
+                          "note": "all physical cores of one socket (BASELINE.md 3.3)"},
+                         {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": CPU_TIMED_MIN,
                           "note": "the reference pod's CPU limit (sample_tfjobs/wav2vec2-dist.yaml)"}],
             "loss_check": check}
 
@@ -312,6 +322,32 @@ def timed_region(one_step, args, strategy, dev, world):
     return float(tmax.item()), float(loss.item()), t_host / args.steps * 1e3
 
 
+def exchange_diagnostics(one_step, args, strategy, dev, world, ms_with, host_ms):
+    """What makes an N > 1 line diagnosable (every rank calls this; collectives inside):
+      rccl_ranks            ranks that really took part: an all-reduce of ones over the job's backend
+      exposed_exchange_ms   ms/step with the gradient exchange - ms/step of the SAME ranks with it left out
+                            (``strategy.exchange_off``; MAX over ranks, same barrier / synchronize bracket): what the
+                            exchange costs beyond the backward it hides under
+      host_enqueue_ms       per rank: host time to enqueue one step (launch-bound ranks show up here)"""
+    import torch
+    import torch.distributed as td
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    td.all_reduce(ones)
+    k = max(5, min(args.steps, 30))
+    sub = argparse.Namespace(steps=k, warmup=2)
+    strategy.exchange_off = True
+    try:
+        dt_off, _, _ = timed_region(one_step, sub, strategy, dev, world)
+    finally:
+        strategy.exchange_off = False
+    hosts = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+    td.all_gather(hosts, torch.tensor([host_ms], dtype=torch.float64, device=dev))
+    ms_off = dt_off / k * 1e3
+    return {"rccl_ranks": int(round(float(ones.item()))), "backend": td.get_backend(),
+            "ms_per_step_without_exchange": ms_off, "exposed_exchange_ms": ms_with - ms_off,
+            "host_enqueue_ms": [float(h.item()) for h in hosts]}
+
+
 def pool_size(global_batch):
     """Clips in the synthetic pool: the reference's 50 (W:792, V:1130) unless the global batch needs more."""
     return max(50, 2 * global_batch)
@@ -337,7 +373,10 @@ def main():
                     help="reference (default on bf16): the reference's training-mode Dropout layers (W:29-30, rates 0.1 / 0.1) are "
                          "active, as in its distributed_train_step (training=True), with counter-based masks; "
                          "off: rates 0, the configuration the loss-curve parity tests pin (and the fp32 path's only mode)")
-    ap.add_argument("--grad_dtype", choices=["fp32", "bf16"], default="fp32", help="wire dtype of the gradient exchange (N > 1)")
+    ap.add_argument("--grad_dtype", choices=["fp32", "bf16"], default=os.environ.get("TMI_GRAD_DTYPE", "fp32"),
+                    help="wire dtype of the gradient exchange (N > 1)")
+    ap.add_argument("--exchange", choices=["allreduce", "rs_ag", "mesh"], default=os.environ.get("TMI_EXCHANGE", "allreduce"),
+                    help="form of the gradient exchange (N > 1): dist.DataParallelStrategy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of timed CPU work for the first thread setting")
@@ -361,7 +400,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     strategy = D.DataParallelStrategy(rank, world, backend=os.environ.get("TETHYS_DIST_BACKEND", "nccl"),
-                                      grad_dtype=args.grad_dtype)
+                                      grad_dtype=args.grad_dtype, exchange=args.exchange)
     drop_note = ("reference rates, counter-based masks" if args.dropout == "reference"
                  else "off (rates 0: the configuration the parity tests pin)")
     dtype_name = "bf16" if args.precision == "bf16" else "f32"
@@ -444,6 +483,10 @@ def main():
     dt, last_loss, host_ms = timed_region(one_step, args, strategy, dev, world)
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step, loss {last_loss:.4f}")
 
+    multi = None
+    if world > 1:
+        multi = exchange_diagnostics(one_step, args, strategy, dev, world, dt / args.steps * 1e3, host_ms)
+
     roof = classes = None
     if not args.no_roofline:
         roof, classes = measure_roofline(model, one_step, min(args.steps, 3), args.precision, tag)
@@ -456,9 +499,12 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": workload, "global_batch": gb, "parallelism": f"dp{world}", "last_loss": last_loss,
                        "dropout": drop_note, "grad_exchange_dtype": args.grad_dtype if world > 1 else None,
+                       "exchange": args.exchange if world > 1 else None,
                        "host_enqueue_ms_per_step": host_ms,
                        "step_tflops": gf_sample * gb * args.steps / dt / 1e3 if gf_sample else None},
         }
+        if multi is not None:
+            out["config"].update(multi)
         if roof is not None:
             out["roofline"] = roof
             out["roofline_classes"] = classes

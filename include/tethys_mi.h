@@ -342,6 +342,10 @@ int tmi_posconv_pack_weights(const float* w, void* wf, void* wb, int64_t k, int6
  * tmi_vq_bwd: dcodebook[g][idx][:] += dq (the only gradient path of the quantiser, V:638). */
 int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx, void* q, float* perplexity,
                    int64_t rows, int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream);
+/* The same quantiser with the code choice given (idx is an INPUT, clamped to [0, Nc)): q = the chosen codes, the same
+ * perplexity.  For replaying a recorded code sequence (teacher-forced parity runs of the bf16 path). */
+int tmi_vq_assign(const float* codebook, const int32_t* idx, void* q, float* perplexity, int64_t rows,
+                  int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G,
                int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 

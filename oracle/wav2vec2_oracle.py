@@ -385,9 +385,10 @@ def adam_step(params, grads, state: AdamState, lr=3e-5, beta1=0.9, beta2=0.999, 
     return _adam(params, grads, state, lr=lr, beta1=beta1, beta2=beta2, eps=eps, eps_mode="tf")
 
 
-def train_steps(cfg, params, pool, batch_size, num_steps, seed=1234, n_replicas=1, lr=3e-5):
+def train_steps(cfg, params, pool, batch_size, num_steps, seed=1234, n_replicas=1, lr=3e-5, code_trace=None):
     """V:1263-1376 loop for ``n_replicas`` replicas on one host.  Returns the printed losses
-    (sum over replicas of loss / n_replicas) and the Adam state."""
+    (sum over replicas of loss / n_replicas) and the Adam state.  ``code_trace``: a list that receives every step's
+    quantiser choices [B, T, G] (teacher-forcing fixture of the bf16 golden test)."""
     rng = np.random.default_rng(seed)
     T = feature_lengths(cfg, pool.shape[1])[-1]
     it = batches(pool, batch_size * n_replicas)
@@ -399,7 +400,9 @@ def train_steps(cfg, params, pool, batch_size, num_steps, seed=1234, n_replicas=
         tot, agg = 0.0, None
         for r in range(n_replicas):
             sl = slice(r * batch_size, (r + 1) * batch_size)
-            loss, g, _ = loss_and_grads(params, torch.from_numpy(a[sl]), torch.from_numpy(neg[sl]), cfg, n_replicas)
+            loss, g, out = loss_and_grads(params, torch.from_numpy(a[sl]), torch.from_numpy(neg[sl]), cfg, n_replicas)
+            if code_trace is not None:
+                code_trace.append(out["code_indices"].to(torch.int32).numpy().copy())
             g, _ = clip_by_global_norm(g, 1.0)  # local, before the all-reduce (V:1243)
             tot += float(loss)
             agg = g if agg is None else {k: agg[k] + g[k] for k in g}

@@ -82,7 +82,6 @@ network profile started!
         os.makedirs(os.path.dirname(model_path), exist_ok=True)
         train.save_weights(model, model_path)
     print(f"{args.model_size.capitalize()} 모델이 {model_path}에 저장되었습니다.")
-    train.wait_for_checkpoints()  # (the epoch-end checkpoint is written behind the job's clock)
     return 0
 
 

@@ -11,6 +11,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import whisper_dist  # noqa: E402
 
-if __name__ == "__main__":
+
+def main(argv=None, model_overrides=None, train_kw=None):
+    """``model_overrides`` / ``train_kw`` are for tests (tiny dimensions), as in whisper_dist.main."""
     logs = os.path.join(os.environ.get("TETHYS_WORKSPACE", "/workspace"), "tensor_logs")
-    sys.exit(whisper_dist.main(sys.argv[1:] + ["--tensor_logs", logs]))
+    argv = list(sys.argv[1:] if argv is None else argv)
+    return whisper_dist.main(argv + ["--tensor_logs", logs], model_overrides=model_overrides, train_kw=train_kw)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

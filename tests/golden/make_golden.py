@@ -49,10 +49,13 @@ def w2v_curve(steps, model_size="base", seed=1234, dtype=torch.float64):
     params = {k: v.to(dtype) for k, v in V.init_params(cfg, seed=seed, dtype=torch.float32).items()}
     pool = V.create_dummy_pool(seed=seed)
     t0 = time.time()
-    losses, _ = V.train_steps(cfg, params, pool, 2, steps, seed=seed + 1, lr=3e-5)
+    trace = []
+    losses, _ = V.train_steps(cfg, params, pool, 2, steps, seed=seed + 1, lr=3e-5, code_trace=trace)
+    # ``code_indices`` [steps][B][T][G]: the oracle's quantiser choices, the teacher-forcing input of the bf16 test (the
+    # hard argmin is discontinuous: a bf16 run on its OWN choices leaves the golden trajectory at the first flipped code)
     return {"model": f"wav2vec2-{model_size} pretraining (V:24-128), 2 s clips", "batch_size": 2, "steps": steps,
             "seed": seed, "neg_seed": seed + 1, "lr": 3e-5, "oracle_dtype": str(dtype), "losses": losses,
-            "oracle_seconds": time.time() - t0}
+            "code_indices": [t.tolist() for t in trace], "oracle_seconds": time.time() - t0}
 
 
 def single_curve(steps=10, seed=1234, dtype=torch.float64):

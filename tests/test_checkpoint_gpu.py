@@ -52,3 +52,56 @@ def test_checkpoint_roundtrip_continues_training(dev, tmp_path):
     m4 = whisper.create_whisper_model("small", device=dev, precision="fp32", **kw2)
     with pytest.raises(ValueError):
         train.load_checkpoint(m4, optim.Adam(1e-3), path)
+
+
+def test_restore_in_place_resets_row_sparse_flags(dev, tmp_path):
+    """Rollback into an (optimizer, model) pair that has already stepped: the row-activity flags of the row-sparse Adam
+    (tmi_adam_step_rows) describe the OLD m / v.  Rows the pre-checkpoint batches touched have non-zero loaded m / v and
+    must keep decaying although the flags of the rolled-back run never saw them: the restored trajectory has to equal the
+    dense (row_sparse = False) one bit for bit."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist, optim, train, whisper
+    kw = dict(d_model=128, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=256, vocab_size=160,
+              encoder_layers=1, decoder_layers=1, n_mels=16, n_ctx=32, decoder_start_token_id=150,
+              max_target_positions=32)
+    rng = np.random.default_rng(1)
+
+    def batch(lo, hi):  # labels drawn from [lo, hi): different batches touch different embedding rows
+        return (torch.from_numpy(rng.standard_normal((2, 16, 48)).astype(np.float32)).to(dev),
+                torch.from_numpy(rng.integers(lo, hi, (2, 12)).astype(np.int32)).to(dev))
+    early = [batch(3, 40), batch(3, 40)]       # rows 3..39 become active, then the checkpoint is taken
+    late = [batch(60, 100), batch(60, 100), batch(60, 100)]
+    strat = dist.DataParallelStrategy(0, 1)
+
+    def run(model, opt, bs):
+        return [float(train.distributed_train_step(strat, model, b, opt).item()) for b in bs]
+
+    # dense reference trajectory
+    md = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=5, **kw)
+    od = optim.Adam(1e-3)
+    od.row_sparse = False
+    run(md, od, early)
+    ref = run(md, od, late)
+
+    # a second pair, row-sparse: steps on OTHER rows first (its flags mark rows 100..149 only), then rolls back in place
+    ms = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=5, **kw)
+    os_ = optim.Adam(1e-3)
+    run(ms, os_, early)
+    path = str(tmp_path / "ck.pt")
+    train.save_checkpoint(ms, os_, path)
+    m2 = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=77, **kw)
+    o2 = optim.Adam(1e-3)
+    run(m2, o2, [batch(100, 150), batch(100, 150)])
+    assert m2.arena.adam_row_flags  # the row-sparse path ran and keeps flags with the arena
+    train.load_checkpoint(m2, o2, path)
+    assert not m2.arena.adam_row_flags and m2.arena.adam_state_dirty
+    got = run(m2, o2, late)
+    assert got == ref, (got, ref)
+    for k in ("p", "m", "v"):
+        assert torch.equal(getattr(m2.arena, k), getattr(md.arena, k)), k
+    # switching the dense kernel on and off again must not resurrect stale flags either
+    o2.row_sparse = False
+    run(m2, o2, [late[0]]); run(md, od, [late[0]])
+    o2.row_sparse = True
+    run(m2, o2, [late[1]]); run(md, od, [late[1]])
+    assert torch.equal(m2.arena.p, md.arena.p) and torch.equal(m2.arena.v, md.arena.v)

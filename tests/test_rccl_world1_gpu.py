@@ -1,0 +1,119 @@
+"""The gradient exchange on the REAL backend (nccl = RCCL) on a one-GPU box: a process group of ONE rank, with the
+strategy's world-1 short-circuits disabled (``DataParallelStrategy(force_collectives=True)``).  A sum over one replica is
+the identity, so every exchange form must leave the step bit for bit what the plain step computes - while the
+machinery that only RCCL exercises runs end to end: asynchronous ``Work`` objects (gloo runs them synchronously,
+``_serial``), the dedicated exchange stream ordered after BOTH producer streams (compute + weight-gradient), staging
+buffers reused across steps, ``all_to_all_single`` followed by the local fold (mesh), ``Work.wait()`` on the exchange
+and optimizer streams, the post lambdas, the on_bucket path (Adam under backward), C2 / C4 and the dmabuf IPC
+environment (``HSA_ENABLE_IPC_MODE_LEGACY=0``).  Reference: W:834 (implicit all-reduce inside apply_gradients), W:848,
+W:1047, V:1468-1475 (NCCL forced).  What a one-rank group cannot show is link behaviour; that needs the 8-GPU node."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# two encoder + two decoder layers: the early-decoder block, the per-layer hand-offs and several buckets are all in play
+KW = dict(d_model=128, encoder_attention_heads=2, decoder_attention_heads=2, d_ff=256, vocab_size=160,
+          encoder_layers=2, decoder_layers=2, n_mels=16, n_ctx=32, decoder_start_token_id=150, max_target_positions=32)
+STEPS = 3
+FORMS = [(ex, dt) for ex in ("allreduce", "rs_ag", "mesh") for dt in ("fp32", "bf16")]
+
+
+def _batches():
+    rng = np.random.default_rng(21)
+    return [(rng.standard_normal((2, 16, 48)).astype(np.float32), rng.integers(0, 150, (2, 12)).astype(np.int32))
+            for _ in range(STEPS)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import tethys_speech_amd  # noqa: F401
+        from tethys_speech_amd import dist as D, optim, train, whisper
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+
+        def run(strat, precision, adam_under_backward=False):
+            model = whisper.create_whisper_model("small", device=dev, precision=precision, seed=11, **KW)
+            assert model._side is not None, "the overlapped step (weight-gradient stream) is what this test is about"
+            strat.broadcast_parameters(model.arena.p)
+            model.refresh_shadows()
+            opt = optim.Adam(1e-3)
+            keep, train.ADAM_UNDER_BACKWARD = train.ADAM_UNDER_BACKWARD, adam_under_backward
+            try:
+                losses = [float(train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)),
+                                                             opt).item()) for f, l in _batches()]
+            finally:
+                train.ADAM_UNDER_BACKWARD = keep
+            torch.cuda.synchronize()
+            return losses, model.arena.p.cpu().numpy(), model.arena.m.cpu().numpy()
+
+        out = {}
+        for precision in ("fp32", "bf16"):
+            out[("plain", precision)] = run(D.DataParallelStrategy(0, 1), precision)
+        first = True
+        for ex, dt in FORMS:
+            # 256 KiB buckets: ~10 buckets per step on this model, launched from inside backward
+            strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=256 * 1024, exchange=ex, grad_dtype=dt,
+                                           force_collectives=True)
+            if first:
+                assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+                ones = torch.ones(8, device=dev)
+                torch.distributed.all_reduce(ones)
+                assert torch.distributed.get_world_size() == 1 and float(ones.sum().item()) == 8.0
+                assert not strat._serial, "RCCL works must stay asynchronous"
+                first = False
+            for precision in ("fp32", "bf16"):
+                out[(ex, dt, precision)] = run(strat, precision)
+        # Adam slice by slice under backward (on_bucket): the optimizer stream waits for each bucket's works
+        strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=256 * 1024, force_collectives=True)
+        out[("under_backward", "fp32")] = run(strat, "fp32", adam_under_backward=True)
+        torch.distributed.destroy_process_group()
+        q.put(("ok", out))
+    except BaseException as e:  # report instead of hanging the parent on q.get
+        import traceback
+        q.put(("error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+def test_rccl_one_rank_exchange_is_the_identity(dev):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(_free_port(), q))
+    p.start()
+    status, out = q.get(timeout=600)
+    p.join(60)
+    assert status == "ok", out
+    for precision in ("fp32", "bf16"):
+        l0, p0, m0 = out[("plain", precision)]
+        for ex, dt in FORMS:
+            l1, p1, m1 = out[(ex, dt, precision)]
+            if dt == "fp32":
+                # fp32 wire: every form moves the bytes unchanged -> the whole trajectory is bit for bit the plain step's
+                assert l1 == l0, (ex, dt, precision, l1, l0)
+                assert np.array_equal(p1, p0) and np.array_equal(m1, m0), (ex, dt, precision)
+            else:
+                # bf16 wire: gradients are rounded to bf16 once on the way (|dg| <= 2^-8 |g|); Adam's first moment after
+                # 3 steps moves by at most that fraction
+                assert np.allclose(l1, l0, rtol=2e-3, atol=2e-3), (ex, dt, precision, l1, l0)
+                den = np.abs(m0).max()
+                assert np.abs(m1 - m0).max() <= 1e-2 * den, (ex, dt, precision, np.abs(m1 - m0).max(), den)
+    l0, p0, m0 = out[("plain", "fp32")]
+    l1, p1, m1 = out[("under_backward", "fp32")]
+    assert l1 == l0 and np.array_equal(p1, p0) and np.array_equal(m1, m0)

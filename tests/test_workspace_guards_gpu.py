@@ -36,6 +36,9 @@ def test_wav2vec2_steps_stay_inside_their_workspace(dev, guarded, precision, dro
     strat = D.DataParallelStrategy(0, 1)
     opt = optim.Adam(learning_rate=1e-4, epsilon=1e-8)
     rng = np.random.default_rng(0)
+    # (400, 2) -> (400, 1) are the shapes of tests/test_wav2vec2_gpu.py::test_whisper_single_step_curve_fp32, the test that
+    # aborted in round 2 (gpurun_out/ab14_tests.log): conv0 output 80 frames = 1 FIR chunk but 2 GroupNorm chunks per sample,
+    # so the backward apply pass wrote B*2*12*C floats into a B*1*12*C buffer (fixed in 8db8fe5, DESIGN (f))
     for T_in, B in ((400, 2), (400, 1), (1600, 3), (400, 2)):  # (T = 20 and 80 frames: one and two chunks per sample)
         pool = V.create_dummy_pool(seed=B, num_samples=B, length=T_in)
         T = V.feature_lengths(ocfg, T_in)[-1]
@@ -46,6 +49,10 @@ def test_wav2vec2_steps_stay_inside_their_workspace(dev, guarded, precision, dro
         assert model.check_workspace_guards() == []
         neg_t = V.sample_negative_indices_roll(rng, T, ocfg.num_negatives)
         loss = train.single_train_step(model, torch.from_numpy(pool).to(dev), torch.from_numpy(neg_t).to(dev), opt)
+        assert np.isfinite(float(loss.item()))
+        assert model.check_workspace_guards() == []
+        # stable_jobs/wav2vec2_dist.py's step (T:1143-1190): the same kernels under the strategy
+        loss = train.stable_wav2vec2_train_step(strat, model, torch.from_numpy(pool).to(dev), torch.from_numpy(neg_t).to(dev), opt)
         assert np.isfinite(float(loss.item()))
         assert model.check_workspace_guards() == []
     model.neg_per_time = False

@@ -94,6 +94,7 @@ SIGNATURES = {
     "tmi_group_unpack": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_posconv_pack_weights": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_vq_assign": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_vq_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_fir_chunks": (c_i64, [c_i64]),
     "tmi_fir_gn_workspace_floats": (c_i64, [c_i64, c_i64, c_i64]),
@@ -113,7 +114,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 _lib = None
 
 

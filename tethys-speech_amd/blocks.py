@@ -180,6 +180,7 @@ class KernelBlocks:
         self._side = torch.cuda.Stream(device=self.device) if on else None
         self._side_handle = self._side.cuda_stream if on else None
         self._side_reads = {}
+        self._done_events = {}
         # events are reused round-robin: creating two per launch costs more host time than the
         # decoder-sized kernels take (re-recording an event other work already waited on is legal)
         self._ev_ring = [torch.cuda.Event() for _ in range(128)] if on else []
@@ -199,7 +200,9 @@ class KernelBlocks:
             fn()
             return
         if ready is None:
-            ready = self._event()
+            # a ring slot is only good for an event that is waited for at once; one that is parked (TMI_DEFER_WGRAD)
+            # could be re-recorded by a later launch before its waiter is enqueued, so it gets an event of its own
+            ready = torch.cuda.Event() if (defer and _DEFER_WGRAD) else self._event()
             ready.record(self._main or torch.cuda.current_stream())  # dy is complete on the main stream here
         if defer and _DEFER_WGRAD:
             self.__dict__.setdefault("_deferred", []).append((fn, dy, ready))
@@ -210,9 +213,15 @@ class KernelBlocks:
             fn()
         finally:
             ops.set_stream(prev)
-        done = self._event()
+        # "done" events are STORED (``_side_reads``) and waited for arbitrarily later - decoder buffers two layers on,
+        # the early-decoder / kv_rest / embedding hand-offs - so they never come from the ring: one event per buffer
+        # address, re-recorded only by a later reader of the same buffer on the same (side) stream, which supersedes it
+        key = dy.data_ptr()
+        done = self._done_events.get(key)
+        if done is None:
+            done = self._done_events[key] = torch.cuda.Event()
         done.record(self._side)
-        self._side_reads[dy.data_ptr()] = done
+        self._side_reads[key] = done
 
     def _flush_deferred(self):
         pend = self.__dict__.get("_deferred")

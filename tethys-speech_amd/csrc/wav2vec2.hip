@@ -579,6 +579,23 @@ __global__ __launch_bounds__(256) void vq_kernel(const T* __restrict__ h, const 
   for (int d = lane; d < gd; d += 64) q[row * G * gd + g * gd + d] = from_f32<T>(cv[d]);
 }
 
+// The quantiser with the code choice GIVEN (tmi_vq_assign): q[row][g] = codebook[g][idx[row][g]].  Teacher-forced runs
+// (a recorded code sequence replayed: the bf16 golden-curve test feeds the fp64 oracle's choices so that the hard
+// argmin's discontinuity does not turn rounding noise into a different trajectory).
+template <typename T>
+__global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ cb, const int32_t* __restrict__ idx,
+                                                        T* __restrict__ q, int64_t rows, int G, int Nc, int gd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * G) return;
+  const int64_t row = item / G;
+  const int g = (int)(item % G);
+  int bi = idx[row * G + g];
+  bi = bi < 0 ? 0 : (bi >= Nc ? Nc - 1 : bi);
+  const float* cv = cb + ((int64_t)g * Nc + bi) * gd;
+  for (int d = lane; d < gd; d += 64) q[row * G * gd + g * gd + d] = from_f32<T>(cv[d]);
+}
+
 // perplexity = mean_g exp(-sum_c p log(p + 1e-10)), p = clip(count / rows, 1e-10, 1)   (V:653-660)
 __global__ __launch_bounds__(256) void vq_perplexity_kernel(const int32_t* __restrict__ idx, float* __restrict__ out,
                                                             int64_t rows, int G, int Nc) {
@@ -990,6 +1007,22 @@ extern "C" int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx
   hipLaunchKernelGGL(vq_perplexity_kernel, dim3(1), dim3(256), (size_t)G * Nc * sizeof(int), s, idx, perplexity, rows,
                      (int)G, (int)Nc);
   return tmi_check_launch("tmi_vq_nearest");
+}
+
+extern "C" int tmi_vq_assign(const float* codebook, const int32_t* idx, void* q, float* perplexity, int64_t rows,
+                             int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream) {
+  if (!codebook || !idx || !q || !perplexity || rows <= 0 || G <= 0 || Nc <= 0 || gd <= 0 || G * Nc > 8192) {
+    tmi_set_error("tmi_vq_assign: bad argument");
+    return TMI_ERR_INVALID;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  dim3 grid((unsigned)((rows * G + 3) / 4));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(vq_assign_kernel<bf16_t>, grid, dim3(256), 0, s, codebook, idx, (bf16_t*)q, rows, (int)G, (int)Nc, (int)gd),
+             hipLaunchKernelGGL(vq_assign_kernel<float>, grid, dim3(256), 0, s, codebook, idx, (float*)q, rows, (int)G, (int)Nc, (int)gd));
+  hipLaunchKernelGGL(vq_perplexity_kernel, dim3(1), dim3(256), (size_t)G * Nc * sizeof(int), s, idx, perplexity, rows,
+                     (int)G, (int)Nc);
+  return tmi_check_launch("tmi_vq_assign");
 }
 
 extern "C" int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G, int64_t Nc,

@@ -77,8 +77,16 @@ class DataParallelStrategy:
 
     def __init__(self, rank: int = 0, world: int = 1, backend: Optional[str] = None,
                  bucket_bytes: int = 24 << 20, init: bool = True, grad_dtype: Optional[str] = None,
-                 exchange: Optional[str] = None):
+                 exchange: Optional[str] = None, force_collectives: bool = False):
         self.rank, self.world = rank, world
+        # ``force_collectives``: issue every collective even with ONE replica (the world-1 short-circuits below are
+        # skipped).  A sum over one rank is the identity, so a step must come out bit for bit as without it - which
+        # lets a one-GPU box run the real RCCL path (nccl backend, Work objects, exchange-stream ordering against both
+        # producer streams, staging buffers) end to end: tests/test_rccl_world1_gpu.py.
+        self.force_collectives = bool(force_collectives)
+        # ``exchange_off``: run the step with the gradient exchange left out (bench.py's N > 1 line times the same ranks
+        # both ways: the difference is the exposed cost of the exchange)
+        self.exchange_off = False
         # launch threshold of the overlapped exchange.  24 MiB: every Whisper small-ref layer (28-38 MB of
         # fp32 gradients) goes out as soon as it is final, so what remains exposed after backward is
         # the conv stem's 8 MB, not "last layer + stem" (the big tensors, lm_head / embeddings at 160 MB,
@@ -94,14 +102,19 @@ class DataParallelStrategy:
         self._stage = {}               # (lo, hi, kind) -> staging tensor, allocated once
         self._pend_lo = self._pend_hi = 0
         self._serial = False           # gloo runs queued works on a thread pool: dependent collectives must be waited for
-        if world > 1 and init and not dist.is_initialized():
+        if (world > 1 or self.force_collectives) and init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             addr, port = rendezvous_from_env()
             os.environ["MASTER_ADDR"] = addr or "127.0.0.1"
             os.environ["MASTER_PORT"] = port or "29531"
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        if world > 1 and dist.is_initialized():
+        if (world > 1 or self.force_collectives) and dist.is_initialized():
             self._serial = dist.get_backend() != "nccl"
+
+    @property
+    def _collective(self) -> bool:
+        """Does this strategy talk to other replicas (or pretend to, ``force_collectives``) in the current step?"""
+        return (self.world > 1 or self.force_collectives) and not self.exchange_off
 
     @property
     def num_replicas_in_sync(self) -> int:
@@ -134,7 +147,7 @@ class DataParallelStrategy:
                        # the bucket's collectives and running its post-step (optim.Adam updates the slice under backward)
 
     def gradients_ready(self, lo: int, hi: int):
-        if self._g is None or (self.world == 1 and self.on_bucket is None):
+        if self._g is None or (not self._collective and self.on_bucket is None):
             return
         if hi != self._pend_lo:
             raise RuntimeError(f"gradient ranges must be contiguous and descending: got [{lo},{hi}) after {self._pend_lo}")
@@ -188,7 +201,7 @@ class DataParallelStrategy:
             ops.set_stream(prev)
 
     def _exchange(self, g: torch.Tensor, lo: int, hi: int):
-        if self.world == 1:
+        if not self._collective:
             works, post = [], None
         else:
             works, post = self._on_exchange_stream(g, lambda: self._exchange_body(g, lo, hi))
@@ -263,7 +276,7 @@ class DataParallelStrategy:
         """C1: SUM over replicas of the whole gradient arena, bucketed.  If ``begin_gradients``
         opened an overlapped exchange for ``g``, only the not-yet-launched head of the arena is
         sent now; in every case this returns with the compute stream ordered after all buckets."""
-        if self.world == 1 and self.on_bucket is None:
+        if not self._collective and self.on_bucket is None:
             self._g = None
             return
         if getattr(self, "_g", None) is g:
@@ -278,7 +291,7 @@ class DataParallelStrategy:
                 w.wait()
             for fn in self._post:
                 fn()
-        if self.world > 1:
+        if self._collective:
             self._on_exchange_stream(g, finish)
             if g.is_cuda:  # the optimizer (compute stream) is the first consumer
                 torch.cuda.current_stream(g.device).wait_stream(self._xs)
@@ -287,15 +300,15 @@ class DataParallelStrategy:
 
     def reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
         """C2: strategy.reduce(SUM, per_replica_losses, axis=None) (W:848)."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dist.all_reduce(x, op=dist.ReduceOp.SUM)
         return x
 
     def broadcast_parameters(self, p: torch.Tensor):
         """C4: replicas start from the chief's initial values."""
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dist.broadcast(p, src=0)
 
     def barrier(self):
-        if self.world > 1:
+        if self.world > 1 or self.force_collectives:
             dist.barrier()

@@ -225,6 +225,7 @@ def softmax_bwd(p, dp, rows, Tk):
 
 
 _ATTN_WS = {}
+_ATTN_WS_RETIRED = []
 
 
 def attn_workspace(device, B, H, Tq):
@@ -236,6 +237,11 @@ def attn_workspace(device, B, H, Tq):
     key = (device.type, device.index, stream())
     ws = _ATTN_WS.get(key)
     if ws is None or ws.numel() < need:
+        # Kernels are launched on the ops-pinned stream, which is not torch's current stream, so the caching allocator
+        # cannot know that a dropped buffer may still be read by queued key-split / combine kernels: a buffer that is
+        # outgrown is parked (never handed back while the process lives; growth happens a handful of times per model)
+        if ws is not None:
+            _ATTN_WS_RETIRED.append(ws)
         ws = _ATTN_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
     return ws
 
@@ -472,6 +478,11 @@ def group_unpack(yg, bias, resid, out, B, T, Cn, G, Tp, row_off):
 def posconv_pack_weights(w, wf, wb, k, Cg, G, w_off=0):
     check(lib().tmi_posconv_pack_weights(w.data_ptr() + 4 * w_off, wf.data_ptr(), wb.data_ptr(), k, Cg, G, dt(wf),
                                          stream()), "tmi_posconv_pack_weights")
+
+
+def vq_assign(codebook, idx, q, perplexity, rows, G, Nc, gd):
+    check(lib().tmi_vq_assign(codebook.data_ptr(), idx.data_ptr(), q.data_ptr(), perplexity.data_ptr(), rows, G, Nc, gd,
+                              dt(q), stream()), "tmi_vq_assign")
 
 
 def vq_nearest(h, codebook, idx, q, perplexity, rows, G, Nc, gd):

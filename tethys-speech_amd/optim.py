@@ -49,12 +49,16 @@ class Adam:
                 ops.adam_step(a.p[s0:s1], a.g[s0:s1], a.m[s0:s1], a.v[s0:s1], s1 - s0, self.learning_rate, self.beta_1,
                               self.beta_2, self.epsilon, self.iterations, self.eps_mode, self.weight_decay, grad_scale,
                               mirror=None if mir is None else mir[s0:s1], zero_grad=zero_grad, max_blocks=max_blocks)
-        tables = (model.embedding_tables()
-                  if (self.row_sparse and self.weight_decay == 0.0 and hasattr(model, "embedding_tables")) else [])
+        sparse_ok = self.row_sparse and self.weight_decay == 0.0 and hasattr(model, "embedding_tables")
+        tables = model.embedding_tables() if sparse_ok else []
+        if not sparse_ok and hasattr(model, "embedding_tables") and a.__dict__.get("adam_row_flags"):
+            self.invalidate_row_flags(model)   # a dense step moves m / v of rows the flags call idle
         pos = lo
         for off, rows, row_len in tables:
             end = off + rows * row_len
             if off < lo or end > hi:   # (a table cut by a bucket boundary: dense)
+                if off < hi and end > lo:
+                    self.invalidate_row_flags(model, off)
                 continue
             dense(pos, off)
             flags = self._row_flags(model, off, rows)
@@ -65,15 +69,30 @@ class Adam:
         dense(pos, hi)
 
     def _row_flags(self, model, off, rows):
-        """One byte per table row, "has m / v ever been non-zero": lives with the optimizer state.  A model whose
-        m / v were loaded from a checkpoint starts with every row marked active (conservative)."""
-        store = self.__dict__.setdefault("_flags", {})
-        key = (id(model), off)
-        f = store.get(key)
+        """One byte per table row, "has m / v ever been non-zero".  The flags describe the m / v arenas, so they live
+        WITH them (``arena.adam_row_flags``, keyed by the table's offset), not in a table keyed by ``id(model)``:
+        whatever overwrites m / v without going through ``tmi_adam_step_rows`` - ``train.load_checkpoint``, a dense
+        update of the table (``row_sparse`` False, or a table cut by a bucket boundary) - calls
+        ``invalidate_row_flags`` and the next row-sparse step starts from "every row active" (conservative: a row
+        with zero m, v and g is left exactly as the dense kernel would leave it, it just is not skipped)."""
+        a = model.arena
+        store = a.__dict__.setdefault("adam_row_flags", {})
+        f = store.get(off)
         if f is None:
-            fresh = self.iterations <= 1
-            f = store[key] = (torch.zeros if fresh else torch.ones)(rows, dtype=torch.uint8, device=model.device)
+            fresh = self.iterations <= 1 and not a.__dict__.get("adam_state_dirty", False)
+            f = store[off] = (torch.zeros if fresh else torch.ones)(rows, dtype=torch.uint8, device=model.device)
         return f
+
+    @staticmethod
+    def invalidate_row_flags(model, off=None):
+        """m / v of the embedding tables (of the one at ``off``) were written by something else than the row-sparse kernel."""
+        a = model.arena
+        store = a.__dict__.setdefault("adam_row_flags", {})
+        if off is None:
+            store.clear()
+        else:
+            store.pop(off, None)
+        a.adam_state_dirty = True
 
     def apply_gradients_clipped(self, model, chunks, sumsq, nseg, clip_global=0.0, clip_each=0.0, grad_scale=1.0,
                                 zero_grad=False):
@@ -142,5 +161,7 @@ class Adam:
         """The update of ``apply_gradients`` with [step_size, vcorr, decay] taken from ``dev_scalars``
         (a 3-float device tensor the caller refreshes from ``scalars()`` before every replay)."""
         a = model.arena
+        if hasattr(model, "embedding_tables"):
+            self.invalidate_row_flags(model)  # dense kernel: the row-activity flags are not kept
         ops.adam_step_dev(a.p, a.g, a.m, a.v, a.numel, self.beta_1, self.beta_2, self.epsilon, dev_scalars,
                           self.eps_mode, grad_scale, mirror=model.mirror)

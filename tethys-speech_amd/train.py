@@ -182,6 +182,9 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
         summ = report.save_final_results()
         report.close()
         log(f"Tiresias tensorsize: {summ['tiresias_tensorsize_mb']:.2f} MB, skewness: {summ['model_skewness']:.3f}")
+    # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
+    # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
+    wait_for_checkpoints()
     model.losses = losses
     return model
 
@@ -245,8 +248,8 @@ _CKPT_THREADS = []
 
 
 def wait_for_checkpoints():
-    """Block until every background checkpoint write has reached the disk (the job shims call this before they return;
-    the interpreter also waits for the writer threads at exit)."""
+    """Block until every background checkpoint write has reached the disk.  Every ``train_*`` loop calls this before it
+    returns, so the JCT a job shim measures around it covers the write, as the reference's does (W:1001-1008)."""
     while _CKPT_THREADS:
         _CKPT_THREADS.pop().join()
 
@@ -287,6 +290,7 @@ def load_checkpoint(model, optimizer, path, dataset=None):
         raise ValueError("checkpoint layout does not match the model")
     a.p.copy_(ck["p"]); a.m.copy_(ck["m"]); a.v.copy_(ck["v"])
     optimizer.iterations = int(ck["iterations"])
+    optimizer.invalidate_row_flags(model)  # the loaded m / v are not the ones the row-activity flags were kept for
     model._drop_step = int(ck.get("drop_step", optimizer.iterations))
     if dataset is not None and ck.get("data_pos") is not None:
         dataset._pos = int(ck["data_pos"])
@@ -394,6 +398,9 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             os.makedirs(checkpoint_dir, exist_ok=True)
             save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"{stem}_epoch_{epoch + 1}.pt"), background=True,
                             dataset=ds, step=step)
+    # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
+    # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
+    wait_for_checkpoints()
     model.losses = losses
     return model
 
@@ -456,6 +463,9 @@ def train_wav2vec2_single(model_type="pretraining", num_epochs=1, learning_rate=
             os.makedirs(checkpoint_dir, exist_ok=True)
             save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"model_epoch_{epoch + 1}.pt"), dataset=ds, step=step,
                             background=True)
+    # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
+    # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
+    wait_for_checkpoints()
     model.losses = losses
     return model
 
@@ -529,6 +539,9 @@ def train_wav2vec2_stable(strategy, model_type="pretraining", num_epochs=1, lear
             os.makedirs(checkpoint_dir, exist_ok=True)
             save_checkpoint(model, optimizer, os.path.join(checkpoint_dir, f"model_epoch_{epoch + 1}.pt"), dataset=ds, step=step,
                             background=True)
+    # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
+    # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
+    wait_for_checkpoints()
     model.losses = losses
     return model
 

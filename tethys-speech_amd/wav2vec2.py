@@ -394,8 +394,13 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         Gq, Nc = cfg.num_codevector_groups, cfg.num_codevectors_per_group
         gd = cfg.codevector_dim // Gq
         self._dense_fwd(hproj, "quantizer.projection.kernel", ws["qin"])
-        ops.vq_nearest(ws["qin"], a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R,
-                       Gq, Nc, gd)
+        forced = self.__dict__.get("forced_codes")
+        if forced is not None:  # teacher-forced run: int32 [B*T, G] codes replace the argmin (tmi_vq_assign)
+            ws["code_idx"].copy_(forced.reshape(ws["code_idx"].shape))
+            ops.vq_assign(a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R, Gq, Nc, gd)
+        else:
+            ops.vq_nearest(ws["qin"], a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R,
+                           Gq, Nc, gd)
         self._dense_fwd(ws["quant"], "project_q.dense.kernel", ws["pq_pre"])
         self._ln_fwd(ws["pq_pre"], "project_q.layer_norm", ws["pq"], "pq_ln")
         if drop:
