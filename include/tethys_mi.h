@@ -96,15 +96,20 @@ int tmi_gemm(const tmi_gemm_desc* d, void* stream);
  * LayerNorm over the last axis of x[rows, C].  Replaces
  * tf.keras.layers.LayerNormalization(epsilon=1e-5) (W:214,216,245,249,253,322,392) and
  * its gradient.  mean/rstd are fp32 [rows], saved for backward.
- * Backward: dgamma[C] / dbeta[C] are ACCUMULATED (fp32 atomics, one per column per
- * workgroup) — the caller zeroes them; dx = (accumulate_dx ? dx : 0) + dLN/dx.
+ * Backward: dgamma[C] / dbeta[C] are ACCUMULATED into (the caller zeroes them); dx = (accumulate_dx ? dx : 0) + dLN/dx.
+ * `workspace` (fp32, 16-byte aligned, >= tmi_layernorm_bwd_workspace_bytes(rows, C, emit) bytes, the caller's): every
+ * workgroup stores its partial column sums there and a second launch on the same stream adds them in workgroup order -
+ * no atomics, bit-reproducible, no slow-down beside other kernels.  workspace == NULL: one fp32 atomic per column per
+ * workgroup (order-dependent last bits; serialises at the memory side under load).
  */
 int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                       float* mean, float* rstd, int64_t rows, int64_t C, float eps,
                       int32_t dtype, void* stream);
+int64_t tmi_layernorm_bwd_workspace_bytes(int64_t rows, int64_t C, int32_t emit);
 int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
-                      int64_t C, int32_t accumulate_dx, int32_t dtype, void* stream);
+                      int64_t C, int32_t accumulate_dx, float* workspace, int64_t workspace_bytes,
+                      int32_t dtype, void* stream);
 
 /* tmi_layernorm_bwd that also emits what the Dense layer BELOW this LayerNorm's residual stream needs from dx (the
  * gradient this kernel writes is that layer's dy): colsum[c] += sum over rows of dy' (its bias gradient), where
@@ -114,7 +119,8 @@ int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
                            int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
-                           float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream);
+                           float dropout_p, uint64_t dropout_seed, float* workspace,
+                           int64_t workspace_bytes, int32_t dtype, void* stream);
 
 /* out[n] += sum over rows of dY[rows, N] (row stride ld): the bias gradient of a Dense /
  * Conv1D layer.  Accumulates with fp32 atomics (one per column per workgroup); the caller

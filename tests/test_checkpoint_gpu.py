@@ -96,12 +96,26 @@ def test_restore_in_place_resets_row_sparse_flags(dev, tmp_path):
     train.load_checkpoint(m2, o2, path)
     assert not m2.arena.adam_row_flags and m2.arena.adam_state_dirty
     got = run(m2, o2, late)
-    assert got == ref, (got, ref)
-    for k in ("p", "m", "v"):
-        assert torch.equal(getattr(m2.arena, k), getattr(md.arena, k)), k
+    assert np.allclose(got, ref, rtol=1e-6, atol=1e-6), (got, ref)
+
+    def same_state(a, b):
+        """Two runs of the same steps agree to the run-to-run noise of the step's fp32 atomics (last bits of the gradients);
+        a row whose m / v stopped decaying or whose weights stopped moving (the stale-flag failure) is off by ~lr per step
+        in p and by 1 - 0.999^k in v - orders of magnitude more."""
+        off, rows, row_len = a.embedding_tables()[0]
+        sl = slice(off, off + rows * row_len)
+        for k, tol in (("p", 1e-5), ("m", 1e-6), ("v", 1e-9)):
+            x, y = getattr(a.arena, k)[sl], getattr(b.arena, k)[sl]
+            assert float((x - y).abs().max()) <= tol + 1e-4 * float(y.abs().max()), (k, float((x - y).abs().max()))
+        assert float((a.arena.p - b.arena.p).abs().max()) <= 1e-5
+    same_state(m2, md)
+    # the rows only the pre-checkpoint batches touched kept moving after the restore (their gradient is zero now)
+    off, rows, row_len = md.embedding_tables()[0]
+    v_rows = m2.arena.v[off:off + rows * row_len].view(rows, row_len)
+    assert float(v_rows[3:40].abs().sum()) > 0
     # switching the dense kernel on and off again must not resurrect stale flags either
     o2.row_sparse = False
     run(m2, o2, [late[0]]); run(md, od, [late[0]])
     o2.row_sparse = True
     run(m2, o2, [late[1]]); run(md, od, [late[1]])
-    assert torch.equal(m2.arena.p, md.arena.p) and torch.equal(m2.arena.v, md.arena.v)
+    same_state(m2, md)

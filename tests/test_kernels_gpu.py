@@ -230,6 +230,61 @@ def test_layernorm(dev, dtype, rows, Cn):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd_partials_are_reproducible_and_accumulate(dev, dtype):
+    """Round 3, the deterministic form (TMI_LN_DETERMINISTIC=1; not the default, see ops.LN_ATOMIC): the per-column sums
+    (dgamma, dbeta, the emitted bias gradient) leave the kernel as one partial row per
+    workgroup in the caller's workspace and are folded in workgroup order by a second launch - no fp32 atomics.  Two
+    launches on the same inputs must therefore agree BIT FOR BIT (the atomic form differed in the last bits from run to
+    run), the sums are ADDED to what the destination holds, and both forms agree to rounding."""
+    ops = _ops()
+    rows, Cn = 12000, 768
+    x = rnd((rows, Cn), dtype, dev, 20, 2.0) + 0.5
+    gamma = rnd((Cn,), torch.float32, dev, 21) + 1.0
+    beta = rnd((Cn,), torch.float32, dev, 22)
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    ops.layernorm_fwd(x, gamma, beta, y, mean, rstd, 1e-5)
+    dy = rnd((rows, Cn), dtype, dev, 23)
+    keep0, ops.LN_ATOMIC = ops.LN_ATOMIC, False   # the deterministic form (TMI_LN_DETERMINISTIC=1)
+    assert ops.ln_bwd_workspace(dev, rows, Cn, True) is not None
+    outs = []
+    for rep in range(3):
+        dx = torch.empty_like(x)
+        dg = torch.full((Cn,), 1.5, dtype=torch.float32, device=dev)   # accumulated into
+        db = torch.full((Cn,), -2.0, dtype=torch.float32, device=dev)
+        cs = torch.full((Cn,), 0.25, dtype=torch.float32, device=dev)
+        masked = torch.empty_like(x)
+        ops.layernorm_bwd_emit(dy, x, gamma, mean, rstd, dx, dg, db, cs, masked=masked, dropout_p=0.1, dropout_seed=99)
+        torch.cuda.synchronize()
+        outs.append((dg.clone(), db.clone(), cs.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)
+    # the plain entry point gives the same dgamma / dbeta (its partial rows have two sums instead of three)
+    dx = torch.empty_like(x)
+    dg = torch.full((Cn,), 1.5, dtype=torch.float32, device=dev)
+    db = torch.full((Cn,), -2.0, dtype=torch.float32, device=dev)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg, db)
+    torch.cuda.synchronize()
+    assert torch.equal(dg, outs[0][0]) and torch.equal(db, outs[0][1])
+    # against the atomic form (workspace == NULL): same sums up to the order of the additions
+    ops.LN_ATOMIC = True
+    try:
+        dg2 = torch.full((Cn,), 1.5, dtype=torch.float32, device=dev)
+        db2 = torch.full((Cn,), -2.0, dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, dg2, db2)
+        torch.cuda.synchronize()
+    finally:
+        ops.LN_ATOMIC = keep0
+    assert rel_err(dg2, dg.double().cpu()) <= 1e-5 and rel_err(db2, db.double().cpu()) <= 1e-5
+    # and the reference value: column sums of dy (dbeta) on top of the initial -2.0
+    ref_db = dy.double().cpu().sum(0) - 2.0
+    assert rel_err(db, ref_db) <= (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,Cn,accumulate,drop", [(4100, 768, True, 0.1), (130, 768, False, 0.0), (1000, 1280, True, 0.25),
                                                      (65, 1024, True, 0.0), (37, 384, False, 0.1)])
 def test_layernorm_bwd_emit(dev, dtype, rows, Cn, accumulate, drop):

@@ -1,6 +1,7 @@
 """The gradient exchange on the REAL backend (nccl = RCCL) on a one-GPU box: a process group of ONE rank, with the
 strategy's world-1 short-circuits disabled (``DataParallelStrategy(force_collectives=True)``).  A sum over one replica is
-the identity, so every exchange form must leave the step bit for bit what the plain step computes - while the
+the identity, so every exchange form must leave the step what the plain step computes (to the run-to-run noise of the
+step's own fp32 atomics, measured here by running the plain step twice) - while the
 machinery that only RCCL exercises runs end to end: asynchronous ``Work`` objects (gloo runs them synchronously,
 ``_serial``), the dedicated exchange stream ordered after BOTH producer streams (compute + weight-gradient), staging
 buffers reused across steps, ``all_to_all_single`` followed by the local fold (mesh), ``Work.wait()`` on the exchange
@@ -68,6 +69,7 @@ def _worker(port, q):
         out = {}
         for precision in ("fp32", "bf16"):
             out[("plain", precision)] = run(D.DataParallelStrategy(0, 1), precision)
+            out[("plain2", precision)] = run(D.DataParallelStrategy(0, 1), precision)  # the step's own run-to-run noise
         first = True
         for ex, dt in FORMS:
             # 256 KiB buckets: ~10 buckets per step on this model, launched from inside backward
@@ -100,20 +102,36 @@ def test_rccl_one_rank_exchange_is_the_identity(dev):
     status, out = q.get(timeout=600)
     p.join(60)
     assert status == "ok", out
+    def close(a, b, what):
+        """Same trajectory up to the step's own run-to-run noise: the weight-gradient / bias-sum kernels add their split-K
+        and per-block partials with fp32 atomics, whose order varies (|dg| ~ 1e-7 |g|), so two PLAIN runs already differ in
+        the last bits.  A missed wait or a stale staging buffer would lose a whole bucket: an Adam step of lr = 1e-3 on
+        every element of it, three orders of magnitude above this bound."""
+        (la, pa, ma), (lb, pb, mb) = a, b
+        assert np.allclose(la, lb, rtol=1e-6, atol=1e-6), (what, la, lb)
+        dp, dm = np.abs(pa - pb), np.abs(ma - mb)
+        # (a gradient that is zero in exact arithmetic - k_proj.bias - is pure summation noise, and Adam turns noise of
+        # the size of its epsilon into a visible step: allow isolated elements, not regions)
+        frac = float((dp > 1e-5).mean())
+        assert frac <= 2e-3 and float(np.median(dp)) <= 1e-7 and float(dm.max()) <= 1e-3 * float(np.abs(mb).max()), \
+            (what, frac, float(dp.max()), float(dm.max()))
+        return float(dp.max())
+
     for precision in ("fp32", "bf16"):
-        l0, p0, m0 = out[("plain", precision)]
+        plain = out[("plain", precision)]
+        noise = close(out[("plain2", precision)], plain, ("plain twice", precision))
+        print(f"{precision}: two plain runs differ by max |dp| = {noise:.1e}")
+        l0, p0, m0 = plain
         for ex, dt in FORMS:
             l1, p1, m1 = out[(ex, dt, precision)]
             if dt == "fp32":
-                # fp32 wire: every form moves the bytes unchanged -> the whole trajectory is bit for bit the plain step's
-                assert l1 == l0, (ex, dt, precision, l1, l0)
-                assert np.array_equal(p1, p0) and np.array_equal(m1, m0), (ex, dt, precision)
+                # fp32 wire: every form moves the bytes unchanged -> the plain step's trajectory
+                d = close(out[(ex, dt, precision)], plain, (ex, dt, precision))
+                print(f"{precision} {ex}/fp32 wire: max |dp| vs the plain step = {d:.1e}")
             else:
                 # bf16 wire: gradients are rounded to bf16 once on the way (|dg| <= 2^-8 |g|); Adam's first moment after
                 # 3 steps moves by at most that fraction
                 assert np.allclose(l1, l0, rtol=2e-3, atol=2e-3), (ex, dt, precision, l1, l0)
                 den = np.abs(m0).max()
                 assert np.abs(m1 - m0).max() <= 1e-2 * den, (ex, dt, precision, np.abs(m1 - m0).max(), den)
-    l0, p0, m0 = out[("plain", "fp32")]
-    l1, p1, m1 = out[("under_backward", "fp32")]
-    assert l1 == l0 and np.array_equal(p1, p0) and np.array_equal(m1, m0)
+    close(out[("under_backward", "fp32")], out[("plain", "fp32")], "Adam under backward")

@@ -106,12 +106,45 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 }
 
 // dgamma/dbeta partials are folded over the block's 8 waves through LDS slabs (LDS float atomics
-// measured 3x slower) and added to the fp32 gradient (zeroed by the caller) with one global atomic
-// per column per block.  Every block adds
-// to the same 2*C addresses, and same-address atomics serialise in L2 (measured: ~10 us per 512
-// blocks at C = 768), so the grid is kept to about one block per CU and each block starts its
-// column walk at a different offset.
+// measured 3x slower).  With a workspace (`part` != nullptr) every block then STORES its row of NRED * C sums to
+// part[block][NRED][C] and ln_fold_kernel, launched right behind on the same stream, adds the rows in block order to the
+// fp32 gradients: no atomics, bit-reproducible, and the cost does not depend on what runs beside it.  (Round 2 measured
+// the atomic form at 0.316 ms/step alone and 0.748 ms/step with the weight-gradient stream saturating L2: every block
+// adds to the same 2-3 * C addresses and same-address atomics serialise at the memory side.)  Without a workspace the
+// atomic form remains: one global atomic per column per block, the column walk started at a different offset per block.
 constexpr int LNB_WAVES = 8;
+
+// out_k[c] += sum over b of part[b][k][c].  A workgroup owns 64 consecutive (k, c) entries; its 16 waves each take the
+// rows b = w, w + 16, ... (at most 16 loads per lane at the default 256 rows, all in flight together: the first version
+// of this fold, one thread per entry walking all rows, was a latency chain of 64 dependent round trips = 12 us per
+// call), then wave 0 adds the 16 wave sums in wave order: a fixed association, so the result is a function of the
+// partials alone.
+constexpr int LNF_WAVES = 16;
+__global__ __launch_bounds__(64 * LNF_WAVES) void ln_fold_kernel(const float* __restrict__ part, int nblocks, int nred, int C,
+                                                                 float* __restrict__ o0, float* __restrict__ o1,
+                                                                 float* __restrict__ o2) {
+  __shared__ float red[LNF_WAVES][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int64_t stride = (int64_t)nred * C;
+  float acc = 0.f;
+  if (i < nred * C) {
+    const float* p = part + i;
+#pragma unroll 8
+    for (int b = w; b < nblocks; b += LNF_WAVES) acc += p[(int64_t)b * stride];
+  }
+  red[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && i < nred * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < LNF_WAVES; ++j) t += red[j][lane];
+    const int k = i / C, c = i - k * C;
+    float* o = k == 0 ? o0 : k == 1 ? o1 : o2;
+    o[c] += t;
+  }
+}
+
 template <typename T, int NCH, bool EMIT = false>
 __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ gamma,
@@ -119,7 +152,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
                                                      T* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int64_t rows, int C,
                                                      int accumulate_dx, float* __restrict__ colsum, T* __restrict__ masked,
-                                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale) {
+                                                     uint32_t drop_key, uint32_t drop_thr, float drop_scale,
+                                                     float* __restrict__ part) {
   // EMIT: the residual-stream gradient this kernel writes (dx) is the dy of the Dense layer below it, whose bias
   // gradient is its column sum - and, where that layer's output went through Dropout (W:205, V:396, V:431), the dy is
   // the MASKED dx.  Both come out of this pass: colsum[c] += sum_rows (masked ? mask*dx : dx), masked[row][c] = mask*dx,
@@ -223,6 +257,17 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     }
   }
   __syncthreads();
+  if (part) {  // this block's row of the partial table: [NRED][C], plain coalesced stores
+    float* prow = part + (int64_t)blockIdx.x * NRED * C;
+    for (int i = threadIdx.x; i < NRED * C; i += 64 * LNB_WAVES) {
+      const int k = i / C, c = i - k * C;
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) a += red[(w * NRED + k) * C + c];
+      prow[i] = a;
+    }
+    return;
+  }
   const int start = (int)((blockIdx.x * 64u) % (unsigned)C);
   for (int i = threadIdx.x; i < C; i += 64 * LNB_WAVES) {
     int c = start + i;
@@ -360,9 +405,22 @@ extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float*
   return tmi_check_launch("tmi_layernorm_fwd");
 }
 
+static int64_t ln_bwd_blocks(int64_t rows) {
+  static const int64_t cap_b = [] { const char* e = getenv("TMI_LN_BWD_BLOCKS"); return e ? atoll(e) : 256ll; }();
+  int64_t rpw = (rows + LNB_WAVES * cap_b - 1) / (LNB_WAVES * cap_b);
+  if (rpw < 2) rpw = 2;  // amortise the per-block dgamma/dbeta fold
+  return (rows + LNB_WAVES * rpw - 1) / (LNB_WAVES * rpw);
+}
+
+extern "C" int64_t tmi_layernorm_bwd_workspace_bytes(int64_t rows, int64_t C, int32_t emit) {
+  if (rows <= 0 || C <= 0) return 0;
+  return ln_bwd_blocks(rows) * (emit ? 3 : 2) * C * (int64_t)sizeof(float);
+}
+
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                          float* dgamma, float* dbeta, int64_t rows, int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
-                         float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream, const char* what) {
+                         float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream, const char* what,
+                         float* workspace, int64_t workspace_bytes) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
       C % vec || !al16(x) || !al16(dy) || !al16(dx) || (masked && (!colsum || !al16(masked) || (C & 1))) ||
@@ -371,11 +429,12 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static const int64_t cap_b = [] { const char* e = getenv("TMI_LN_BWD_BLOCKS"); return e ? atoll(e) : 256ll; }();
-  int64_t rpw = (rows + LNB_WAVES * cap_b - 1) / (LNB_WAVES * cap_b);
-  if (rpw < 2) rpw = 2;  // amortise the per-block dgamma/dbeta fold
-  const int64_t blocks = (rows + LNB_WAVES * rpw - 1) / (LNB_WAVES * rpw);
+  const int64_t blocks = ln_bwd_blocks(rows);
   const bool emit = colsum != nullptr;
+  if (workspace && (workspace_bytes < tmi_layernorm_bwd_workspace_bytes(rows, C, emit) || !al16(workspace))) {
+    tmi_set_error("tmi_layernorm_bwd: workspace smaller than tmi_layernorm_bwd_workspace_bytes() or misaligned");
+    return TMI_ERR_INVALID;
+  }
   const size_t lds = (size_t)LNB_WAVES * (emit ? 3 : 2) * C * sizeof(float);  // <= 128 KiB (192 with emission) at C = 2048
   if (emit && lds > 160 * 1024) {
     tmi_set_error("tmi_layernorm_bwd_emit: C too wide for the three-way fold");
@@ -393,7 +452,8 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LNB_WAVES * (EM ? 3 : 2) * LN_MAX_C * 4 > 160 * 1024 ? 160 * 1024 : LNB_WAVES * (EM ? 3 : 2) * LN_MAX_C * 4);
     (void)attr;
     hipLaunchKernelGGL((ln_bwd_kernel<T, N, EM>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s, (const T*)dy, (const T*)x,
-                       gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx, colsum, (T*)mk, key, thr, scale);
+                       gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx, colsum, (T*)mk, key, thr, scale,
+                       workspace);
   };
   if (dtype == TMI_BF16) {
     ln_dispatch<bf16_t>(C, [&](auto nch) {
@@ -408,26 +468,34 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   } else {
     return TMI_ERR_UNSUPPORTED;
   }
+  if (workspace) {
+    int rc = tmi_check_launch(what);
+    if (rc) return rc;
+    const int nred = emit ? 3 : 2;
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((unsigned)((nred * C + 63) / 64)), dim3(64 * LNF_WAVES), 0, s, workspace, (int)blocks,
+                       nred, (int)C, dgamma, dbeta, colsum);
+  }
   return tmi_check_launch(what);
 }
 
 extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
-                                 int32_t accumulate_dx, int32_t dtype, void* stream) {
+                                 int32_t accumulate_dx, float* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, nullptr, nullptr, 0.f, 0, dtype, stream,
-                       "tmi_layernorm_bwd");
+                       "tmi_layernorm_bwd", workspace, workspace_bytes);
 }
 
 extern "C" int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
                                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                                       int32_t accumulate_dx, float* colsum, void* masked, float dropout_p,
-                                      uint64_t dropout_seed, int32_t dtype, void* stream) {
+                                      uint64_t dropout_seed, float* workspace, int64_t workspace_bytes, int32_t dtype,
+                                      void* stream) {
   if (!colsum) {
     tmi_set_error("tmi_layernorm_bwd_emit: colsum is required");
     return TMI_ERR_INVALID;
   }
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, colsum, masked, dropout_p, dropout_seed,
-                       dtype, stream, "tmi_layernorm_bwd_emit");
+                       dtype, stream, "tmi_layernorm_bwd_emit", workspace, workspace_bytes);
 }
 
 extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,

@@ -7,6 +7,7 @@ stream.  Nothing here computes on the host or falls back to torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -174,13 +175,40 @@ def layernorm_fwd(x2d, gamma, beta, y2d, mean, rstd, eps):
               "tmi_layernorm_fwd")
 
 
+_LN_WS = {}
+# tmi_layernorm_bwd's column sums: fp32 atomics (default) or per-workgroup partial rows in a workspace + a fixed-order
+# fold launch (TMI_LN_DETERMINISTIC=1: bit-reproducible dgamma / dbeta / bias sums).  Measured on MI355X, round 3
+# (profiles/r03_ln_bwd_forms.txt): the two forms take the same time alone (23-24 us at [12000, 768] bf16) AND beside the
+# weight-gradient stream (88-108 us either way: the kernel is starved of CUs by the one-workgroup-per-CU GEMMs, it is
+# not serialising on its atomics), and the extra launch per call costs the step 0.07-0.1 ms - so atomics stay the default.
+LN_ATOMIC = os.environ.get("TMI_LN_DETERMINISTIC", "0") == "0"
+
+
+def ln_bwd_workspace(device, rows, C, emit):
+    """Partial-sum table of tmi_layernorm_bwd (one row of 2-3 * C floats per workgroup): one per (device, stream) like the
+    GEMM workspace - the fold launch that reads it follows on the same stream.  An outgrown buffer is parked, never
+    returned to the allocator while queued kernels may read it (see attn_workspace)."""
+    if LN_ATOMIC:
+        return None
+    need = int(lib().tmi_layernorm_bwd_workspace_bytes(rows, C, 1 if emit else 0))
+    key = (device.type, device.index, stream())
+    ws = _LN_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _ATTN_WS_RETIRED.append(ws)
+        ws = _LN_WS[key] = torch.empty(max(need // 4, 1 << 20), dtype=torch.float32, device=device)
+    return ws
+
+
 def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, accumulate_dx=False):
-    """dgamma / dbeta are accumulated (atomics): zero them first (the grad arena is)."""
+    """dgamma / dbeta are accumulated into: zero them first (the grad arena is)."""
     with _probe("layernorm", (4.0 if accumulate_dx else 3.0) * x2d.numel() * x2d.element_size()):
         rows, Cn = x2d.shape
+        ws = ln_bwd_workspace(x2d.device, rows, Cn, False)
         check(lib().tmi_layernorm_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
-                                      1 if accumulate_dx else 0, dt(x2d), stream()), "tmi_layernorm_bwd")
+                                      1 if accumulate_dx else 0, ptr(ws), 0 if ws is None else ws.numel() * 4, dt(x2d), stream()),
+              "tmi_layernorm_bwd")
 
 
 def layernorm_bwd_emit(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, colsum, masked=None, dropout_p=0.0, dropout_seed=0,
@@ -191,10 +219,11 @@ def layernorm_bwd_emit(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, colsum
     work = ((4.0 if accumulate_dx else 3.0) + (1.0 if masked is not None and dropout_p > 0 else 0.0)) * x2d.numel() * es
     with _probe("layernorm", work):
         rows, Cn = x2d.shape
+        ws = ln_bwd_workspace(x2d.device, rows, Cn, True)
         check(lib().tmi_layernorm_bwd_emit(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                            dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
                                            1 if accumulate_dx else 0, colsum.data_ptr(), ptr(masked), dropout_p, dropout_seed,
-                                           dt(x2d), stream()), "tmi_layernorm_bwd_emit")
+                                           ptr(ws), 0 if ws is None else ws.numel() * 4, dt(x2d), stream()), "tmi_layernorm_bwd_emit")
 
 
 def bias_grad(dy2d, dbias):
