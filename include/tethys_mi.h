@@ -114,8 +114,10 @@ int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 /* tmi_layernorm_bwd that also emits what the Dense layer BELOW this LayerNorm's residual stream needs from dx (the
  * gradient this kernel writes is that layer's dy): colsum[c] += sum over rows of dy' (its bias gradient), where
  * dy' = dx, or - when that layer's output went through Dropout (W:205, V:396, V:431) - dy' = mask * dx / (1 - p), which is
- * also written to `masked` [rows][C] (the generator of tmi_dropout over [rows, C] with `dropout_seed`).  masked == NULL or
- * dropout_p == 0: no mask, column sums of dx.  Replaces a tmi_dropout and a tmi_colsum pass over dx. */
+ * also written to `masked` [rows][C] (the generator of tmi_dropout over [rows, C] with `dropout_seed`).  masked == NULL:
+ * no copy, column sums of dx; masked != NULL with dropout_p == 0: column sums of dx and a plain second copy of dx in
+ * `masked` (a snapshot for a weight gradient launched after dx has been overwritten).  Replaces a tmi_dropout and a
+ * tmi_colsum pass over dx. */
 int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
                            const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,
                            int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
@@ -127,6 +129,10 @@ int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, co
  * zeroes `out`. */
 int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N,
                int32_t dtype, void* stream);
+/* nbatch matrices dy + b * dy_sb (elements) into nbatch vectors out + b * out_sb in one launch: the bias gradients of the
+ * same Dense layer in every transformer layer (deferred, batched weight gradients). */
+int tmi_colsum_batched(const void* dy, int64_t ld, int64_t dy_sb, float* out, int64_t out_sb,
+                       int64_t rows, int64_t N, int64_t nbatch, int32_t dtype, void* stream);
 
 /* dx = dy * gelu_erf'(u), elementwise over n elements (backward of W:336 where the GELU
  * output feeds the positional add rather than a GEMM). */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "tmi_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp]),
     "tmi_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
+    "tmi_colsum_batched": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_gelu_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
     "tmi_dropout": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_f32, C.c_uint64, c_i32, c_vp]),
     "tmi_gelu_bwd_batched": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_vp]),
@@ -115,7 +116,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 _lib = None
 
 

@@ -300,6 +300,39 @@ class KernelBlocks:
             self.ws[name] = t
         return t
 
+    def _buf_layers(self, prefix, L, name, shape, dtype=None):
+        """Per-layer buffers ``{prefix}{i}.{name}`` as slices of ONE [L, *shape] allocation: a constant layer stride, so a
+        batched GEMM (tmi_gemm's nbatch) can walk the same operand of every layer in one launch (_wgrad_batched)."""
+        st = self._buf(f"{prefix}*.{name}", (max(L, 1),) + tuple(shape), dtype)
+        for i in range(L):
+            self.ws[f"{prefix}{i}.{name}"] = st[i]
+        return st
+
+    def _layer_stride(self, name_fmt, L):
+        """Arena distance between the same variable of consecutive layers (the arena lays every layer out alike)."""
+        offs = [self.arena.offsets[name_fmt.format(i)] for i in range(L)]
+        stride = offs[1] - offs[0] if L > 1 else 0
+        if any(offs[i + 1] - offs[i] != stride for i in range(L - 1)):
+            raise RuntimeError(f"{name_fmt}: layers are not at a constant arena stride")
+        return stride
+
+    def _wgrad_batched(self, x_stack, dy_stack, wname_fmt, L, bias=True):
+        """dW_l = x_lᵀ · dy_l (and db_l = colsum(dy_l)) for every layer l in ONE launch each: the deferred form of
+        ``_dense_bwd``'s weight gradient.  At M = B * 100 rows a layer's weight gradient is a 13-26 us launch that cannot
+        fill the chip (Wav2Vec2: 58 of them per step, the Whisper decoder 24); L of them side by side are one GEMM with L
+        times the tiles.  x_stack [L, M, K_in], dy_stack [L, M, N] (``_buf_layers``); the gradient arena supplies the
+        constant stride on the output side."""
+        a = self.arena
+        w0 = wname_fmt.format(0)
+        K_in, N = a.shapes[w0][-2], a.shapes[w0][-1]
+        M = x_stack.shape[1]
+        stride = self._layer_stride(wname_fmt, L)
+        ops.gemm(x_stack, dy_stack, a.grad(w0).view(K_in, N), K_in, N, M, 1, x_stack.stride(1), dy_stack.stride(1), 1, N,
+                 nbatch=L, a_sb=x_stack.stride(0), b_sb=dy_stack.stride(0), c_sb=stride, splitk=0)
+        b0 = w0.replace(".kernel", ".bias")
+        if bias and b0 in a.offsets:
+            ops.bias_grad_batched(dy_stack, a.grad(b0), self._layer_stride(wname_fmt.replace(".kernel", ".bias"), L))
+
     def check_workspace_guards(self):
         """Names of workspace buffers whose guard zone (TMI_WS_GUARD=<elements>) was written: a kernel ran past their end."""
         torch.cuda.synchronize()
@@ -318,7 +351,7 @@ class KernelBlocks:
                       bias=bias, **epi)
 
     def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False,
-                   dgrad_epi=None, bias_done=False, defer=False):
+                   dgrad_epi=None, bias_done=False, defer=False, wgrad=True):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
         ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
         before its consumer), so the dgrad goes to the weight-gradient stream too."""
@@ -343,7 +376,8 @@ class KernelBlocks:
             self._guard_write(dx2d)
             self._run_on_side(lambda: (weight_grads(), dgrad()), dy2d)
             return
-        self._run_on_side(weight_grads, dy2d, defer=defer)
+        if wgrad:  # (False: the caller batches this layer's weight gradient with the other layers', _wgrad_batched)
+            self._run_on_side(weight_grads, dy2d, defer=defer)
         if dx2d is not None:
             self._guard_write(dx2d)
             dgrad()
@@ -356,7 +390,8 @@ class KernelBlocks:
     def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate, emit=None):
         """``emit`` = (bias gradient tensor, masked-copy buffer or None, dropout site or None): the Dense layer below this
         LayerNorm takes dx (or its Dropout-masked copy) as dy; its bias gradient and the masked copy come out of this
-        kernel (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dx."""
+        kernel (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dx.  A buffer without
+        dropout (rate 0 or no site) receives a plain copy of dx: the snapshot a deferred weight gradient reads."""
         a = self.arena
         self._guard_write(dx2d)
         if emit is None:
@@ -368,7 +403,7 @@ class KernelBlocks:
         if masked is not None:
             self._guard_write(masked)
         ops.layernorm_bwd_emit(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"], dx2d,
-                               a.grad(pname + ".gamma"), a.grad(pname + ".beta"), colsum, masked=masked if p > 0 else None,
+                               a.grad(pname + ".gamma"), a.grad(pname + ".beta"), colsum, masked=masked,
                                dropout_p=p, dropout_seed=self._site_seed(site) if p > 0 else 0, accumulate_dx=accumulate)
 
     # ---- dropout (training mode of the reference, W:160 / W:205 / W:342 / W:411): counter-based masks

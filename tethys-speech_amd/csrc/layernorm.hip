@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     }
     IO::store(dx + row * C, C, lane, dv);
     if constexpr (EMIT) {
-      if (masked) {
+      if (masked && drop_thr) {
         const tmi_rowkey rk = tmi_row_key(drop_key, (uint32_t)row);
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -238,8 +238,10 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
             dv[e + 1] = (hh >> 16) >= drop_thr ? dv[e + 1] * drop_scale : 0.f;
           }
         }
-        IO::store(masked + row * C, C, lane, dv);
       }
+      // (drop_thr == 0 with a `masked` buffer: a plain second copy of dx - a snapshot for a weight gradient that is
+      // launched after this buffer has been overwritten, tmi_layernorm_bwd_emit)
+      if (masked) IO::store(masked + row * C, C, lane, dv);
 #pragma unroll
       for (int e = 0; e < E; ++e) dc[e] += dv[e];
     }
@@ -310,8 +312,10 @@ inline void ln_dispatch(int64_t C, F&& f) {
 constexpr int CS_WAVES = 8;
 template <typename T>
 __global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const T* __restrict__ dy, int64_t ld, float* __restrict__ out,
-                                                               int64_t rows, int64_t N) {
+                                                               int64_t rows, int64_t N, int64_t dy_sb, int64_t out_sb) {
   constexpr int VEC = 16 / sizeof(T);
+  dy += (int64_t)blockIdx.z * dy_sb;    // batch (tmi_colsum_batched): one matrix and one output vector per z
+  out += (int64_t)blockIdx.z * out_sb;
   __shared__ float red[CS_WAVES][64 * VEC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * VEC;
@@ -443,7 +447,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   const uint32_t thr = masked ? tmi_drop_thr(dropout_p) : 0u;
   const uint32_t key = tmi_stream_key(dropout_seed, 0u);
   const float scale = tmi_keep_scale(thr);
-  void* mk = (masked && thr) ? masked : nullptr;  // p == 0: the "masked" copy is dx itself; only the column sum is emitted
+  void* mk = masked;  // p == 0: the copy is dx itself (a snapshot for a deferred reader)
   auto go = [&](auto tag_t, auto nch, auto em) {
     using T = decltype(tag_t);
     constexpr int N = decltype(nch)::value;
@@ -498,28 +502,34 @@ extern "C" int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float
                        dtype, stream, "tmi_layernorm_bwd_emit", workspace, workspace_bytes);
 }
 
-extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
-                          void* stream) {
+extern "C" int tmi_colsum_batched(const void* dy, int64_t ld, int64_t dy_sb, float* out, int64_t out_sb, int64_t rows, int64_t N,
+                                  int64_t nbatch, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
-  if (!dy || !out || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy)) {
-    tmi_set_error("tmi_colsum: bad argument (N and ld must be multiples of 16 bytes)");
+  if (!dy || !out || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy) || nbatch <= 0 || nbatch > 65535 ||
+      (nbatch > 1 && dy_sb % vec)) {
+    tmi_set_error("tmi_colsum: bad argument (N, ld and the batch stride must be multiples of 16 bytes)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t xb = (N + 64 * vec - 1) / (64 * vec);
   static const int64_t cs_blocks = [] { const char* e = getenv("TMI_COLSUM_BLOCKS"); return e ? atoll(e) : 128ll; }();
   int64_t yb = (rows + CS_WAVES * 4 - 1) / (CS_WAVES * 4);  // at least four rows per wave
-  const int64_t cap = (cs_blocks + xb - 1) / xb;
+  const int64_t cap = (cs_blocks + xb * nbatch - 1) / (xb * nbatch);
   if (yb > cap) yb = cap;
   if (yb < 1) yb = 1;
-  dim3 grid((unsigned)xb, (unsigned)yb);
+  dim3 grid((unsigned)xb, (unsigned)yb, (unsigned)nbatch);
   if (dtype == TMI_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64 * CS_WAVES), 0, s, (const bf16_t*)dy, ld, out, rows, N);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64 * CS_WAVES), 0, s, (const bf16_t*)dy, ld, out, rows, N, dy_sb, out_sb);
   else if (dtype == TMI_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64 * CS_WAVES), 0, s, (const float*)dy, ld, out, rows, N);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(64 * CS_WAVES), 0, s, (const float*)dy, ld, out, rows, N, dy_sb, out_sb);
   else
     return TMI_ERR_UNSUPPORTED;
   return tmi_check_launch("tmi_colsum");
+}
+
+extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
+                          void* stream) {
+  return tmi_colsum_batched(dy, ld, 0, out, 0, rows, N, 1, dtype, stream);
 }
 
 extern "C" int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,

@@ -234,6 +234,14 @@ def bias_grad(dy2d, dbias):
               "tmi_colsum")
 
 
+def bias_grad_batched(dy3d, dbias, out_sb):
+    """dy3d [L, rows, N] (constant layer stride) -> dbias + l * out_sb (elements) += column sums of dy3d[l], one launch."""
+    with _probe("colsum", 1.0 * dy3d.numel() * dy3d.element_size()):
+        L, rows, N = dy3d.shape
+        check(lib().tmi_colsum_batched(dy3d.data_ptr(), dy3d.stride(1), dy3d.stride(0), dbias.data_ptr(), out_sb, rows, N, L,
+                                       dt(dy3d), stream()), "tmi_colsum_batched")
+
+
 def gelu_bwd(dy, u, dx):
     check(lib().tmi_gelu_bwd(dy.data_ptr(), u.data_ptr(), dx.data_ptr(), dy.numel(), dt(dy), stream()),
           "tmi_gelu_bwd")

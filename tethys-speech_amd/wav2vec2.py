@@ -270,10 +270,16 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self._buf("ph_pre", (R, pd)); self._buf("ph", (R, pd))
         self._buf("ph_ln.mean", (R,), f32); self._buf("ph_ln.rstd", (R,), f32)
         ff = cfg.intermediate_size
-        for i in range(cfg.num_hidden_layers):
+        Lh = cfg.num_hidden_layers
+        # the operands of the layers' weight gradients live at a constant layer stride (one allocation per kind): the saved
+        # forward activations xn1 / ctx / xn2 / g and the gradients dqkv / dya / dU / dyf each Dense layer receives, so that
+        # after the backward loop ONE batched GEMM per kind computes that weight gradient for all layers (_wgrad_batched)
+        for n, shp in (("xn1", (R, H)), ("ctx", (R, H)), ("xn2", (R, H)), ("g", (R, ff)),
+                       ("dqkv", (R, 3 * H)), ("dya", (R, H)), ("dU", (R, ff)), ("dyf", (R, H))):
+            self._buf_layers("enc", Lh, n, shp)
+        for i in range(Lh):
             p = f"enc{i}."
-            for n, shp in (("x_in", (R, H)), ("xn1", (R, H)), ("qkv", (R, 3 * H)), ("ctx", (R, H)), ("x_mid", (R, H)),
-                           ("xn2", (R, H)), ("u", (R, ff)), ("g", (R, ff))):
+            for n, shp in (("x_in", (R, H)), ("qkv", (R, 3 * H)), ("x_mid", (R, H)), ("u", (R, ff))):
                 self._buf(p + n, shp)
             for s_ in ("ln1", "ln2"):
                 self._buf(p + s_ + ".mean", (R,), f32); self._buf(p + s_ + ".rstd", (R,), f32)
@@ -289,10 +295,6 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self._buf("loss", (1,), f32)
         # backward scratch
         self._buf("dres", (R, H)); self._buf("dtmp", (R, H)); self._buf("dctx", (R, H))
-        if self._drop_p > 0.0:  # masked gradient copies (dropout mode), alternating by layer: see whisper.py
-            for nm in ("dyd_f0", "dyd_f1", "dyd_a0", "dyd_a1"):
-                self._buf(nm, (R, H))
-        self._buf("dqkv", (R, 3 * H)); self._buf("dU", (R, ff))
         self._buf("dph", (R, pd)); self._buf("dpq", (R, pd)); self._buf("dpd", (R, pd)); self._buf("dpd_q", (R, pd))
         self._buf("dquant", (R, cd))
         self._buf("dfeats", (R, C)); self._buf("dhp", (R, C)); self._buf("dh_last", (R, C))
@@ -472,51 +474,87 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dres.  TMI_LN_EMIT=0: separate kernels.
         emit_on = os.environ.get("TMI_LN_EMIT", "1") != "0"
         Lh = cfg.num_hidden_layers
+        # Weight gradients of the encoder: deferred and batched over the layers (TMI_WGRAD_BATCH=0: one launch per layer
+        # beside its dgrad, the round-2 form).  Every Dense layer's dy is kept in a per-layer buffer - dqkv / dU are written
+        # there by the kernels that produce them, the residual-stream gradients (dyf for output_dense, dya for out_proj) are
+        # the second output of the LayerNorm backward above them (its Dropout-masked copy, or a plain copy at rate 0).
+        batch = os.environ.get("TMI_WGRAD_BATCH", "1") != "0" and Lh > 1
 
         def emit(bias_name, buf, site):
-            return (a.grad(bias_name), ws[buf] if drop else None, site) if emit_on else None
+            return (a.grad(bias_name), ws[buf] if (drop or batch) else None, site) if emit_on else None
+
+        def residual_dy(i, kind, site, have):
+            """The dy a Dense layer on the residual stream sees: ``dres`` itself, its masked copy (dropout), or - when the
+            weight gradient is deferred - a snapshot, since ``dres`` is rewritten by the next LayerNorm backward.
+            ``have``: the LayerNorm backward that produced ``dres`` already wrote the per-layer buffer."""
+            if not (drop or batch):
+                return dres
+            dy = ws[f"enc{i}.{kind}"]
+            if not have:
+                if drop:
+                    self._dropout(dres, dy, site)
+                else:
+                    self._guard_write(dy)
+                    dy.copy_(dres)
+            return dy
 
         for i in reversed(range(Lh)):
             p, kk = f"encoder.layers.{i}", f"enc{i}."
-            dU, dt_, dctx, dqkv = ws["dU"], ws["dtmp"], ws["dctx"], ws["dqkv"]
+            dU, dt_, dctx, dqkv = ws[kk + "dU"], ws["dtmp"], ws["dctx"], ws[kk + "dqkv"]
             top = i == Lh - 1  # (the top layer's dres comes from the projection head's dgrad, not from a LayerNorm)
-            dy = dres
-            if drop:  # the branch sees the masked gradient (same mask, regenerated)
-                dy = ws[f"dyd_f{i & 1}"]
-                if top or not emit_on:
-                    self._dropout(dres, dy, SITE_FFN_OUT + i)
+            dy = residual_dy(i, "dyf", SITE_FFN_OUT + i, emit_on and not top)  # the branch sees the masked gradient
             # d u = gelu'(u) * mask/keep * d g: both factors are epilogue terms of the dgrad (elementwise factors commute)
             self._dense_bwd(ws[kk + "g"], dy, p + ".feed_forward.output_dense.kernel", dU, aux_in=ws[kk + "u"],
-                            dgrad_epi=self._drop_epi(SITE_FFN_MID + i, p=pa), bias_done=emit_on and not top)
-            self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_)
+                            dgrad_epi=self._drop_epi(SITE_FFN_MID + i, p=pa), bias_done=emit_on and not top, wgrad=not batch)
+            self._dense_bwd(ws[kk + "xn2"], dU, p + ".feed_forward.intermediate_dense.kernel", dt_, wgrad=not batch)
             self._ln_bwd(dt_, ws[kk + "x_mid"], p + ".feed_forward_layer_norm", dres, kk + "ln2", True,
-                         emit=emit(p + ".attention.out_proj.bias", f"dyd_a{i & 1}", SITE_ATTN_OUT + i))
-            dy = dres
-            if drop:
-                dy = ws[f"dyd_a{i & 1}"]
-                if not emit_on:
-                    self._dropout(dres, dy, SITE_ATTN_OUT + i)
-            self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx, bias_done=emit_on)
+                         emit=emit(p + ".attention.out_proj.bias", kk + "dya", SITE_ATTN_OUT + i))
+            dy = residual_dy(i, "dya", SITE_ATTN_OUT + i, emit_on)
+            self._dense_bwd(ws[kk + "ctx"], dy, p + ".attention.out_proj.kernel", dctx, bias_done=emit_on, wgrad=not batch)
             qkv = ws[kk + "qkv"]
             self._attn_bwd(kk + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, H), (qkv, 2 * H),
                            ws[kk + "ctx"], dctx, (dqkv, 0), (dqkv, H), (dqkv, 2 * H), B, Hh, T, T, 0, score_scale=sscale,
                            q_prescaled=False, site=SITE_ATTN + i)
             # three separate kernels: wgrad / bias grad batched over the blocks, dgrad summed over them
             wq, _ = self.W(p + ".attention.qkv3.kernel")
-            gq = a.grad(p + ".attention.qkv3.kernel")
-            xn1 = ws[kk + "xn1"]
-            gqb = a.grad(p + ".attention.qkv3.bias").view(3 * H)
+            if not batch:
+                gq = a.grad(p + ".attention.qkv3.kernel")
+                xn1 = ws[kk + "xn1"]
+                gqb = a.grad(p + ".attention.qkv3.bias").view(3 * H)
 
-            def qkv_weight_grads(xn1=xn1, gq=gq, gqb=gqb):
-                ops.gemm(xn1, dqkv, gq, H, H, R, 1, H, 3 * H, 1, H, nbatch=3, b_sb=H, c_sb=H * H, splitk=0)
-                ops.bias_grad(dqkv, gqb)
+                def qkv_weight_grads(xn1=xn1, gq=gq, gqb=gqb, dqkv=dqkv):
+                    ops.gemm(xn1, dqkv, gq, H, H, R, 1, H, 3 * H, 1, H, nbatch=3, b_sb=H, c_sb=H * H, splitk=0)
+                    ops.bias_grad(dqkv, gqb)
 
-            self._run_on_side(qkv_weight_grads, dqkv)
+                self._run_on_side(qkv_weight_grads, dqkv)
             self._guard_write(dt_)
             ops.gemm(dqkv, wq, dt_, R, H, H, 3 * H, 1, 1, H, H, kbatch=3, a_skb=H, b_skb=H * H)
             self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True,
-                         emit=emit(f"encoder.layers.{i - 1}.feed_forward.output_dense.bias", f"dyd_f{(i - 1) & 1}",
+                         emit=emit(f"encoder.layers.{i - 1}.feed_forward.output_dense.bias", f"enc{i - 1}.dyf",
                                    SITE_FFN_OUT + i - 1) if i > 0 else None)
+
+        if batch:
+            st = {n: ws[f"enc*.{n}"] for n in ("xn1", "ctx", "xn2", "g", "dqkv", "dya", "dU", "dyf")}
+            lay = "encoder.layers.{}"
+
+            def encoder_weight_grads():
+                # the bias gradients the LayerNorm backward did not emit: every layer's with TMI_LN_EMIT=0, the top layer's
+                # output_dense otherwise (its dres came from the projection head)
+                self._wgrad_batched(st["g"], st["dyf"], lay + ".feed_forward.output_dense.kernel", Lh, bias=not emit_on)
+                if emit_on:
+                    ops.bias_grad(st["dyf"][Lh - 1], a.grad(lay.format(Lh - 1) + ".feed_forward.output_dense.bias"))
+                self._wgrad_batched(st["xn2"], st["dU"], lay + ".feed_forward.intermediate_dense.kernel", Lh)
+                self._wgrad_batched(st["ctx"], st["dya"], lay + ".attention.out_proj.kernel", Lh, bias=not emit_on)
+                # the q / k / v blocks are three [H, H] kernels side by side in the arena: one launch per block over all layers
+                gq0 = a.grad(lay.format(0) + ".attention.qkv3.kernel")
+                lstride = self._layer_stride(lay + ".attention.qkv3.kernel", Lh)
+                for j in range(3):
+                    ops.gemm(st["xn1"], st["dqkv"], gq0, H, H, R, 1, H, 3 * H, 1, H, nbatch=Lh, a_sb=R * H, b_sb=R * 3 * H,
+                             c_sb=lstride, b_off=j * H, c_off=j * H * H, splitk=0)
+                ops.bias_grad_batched(st["dqkv"], a.grad(lay.format(0) + ".attention.qkv3.bias"),
+                                      self._layer_stride(lay + ".attention.qkv3.bias", Lh))
+            # under the feature-projection / positional-conv / conv-stack backward that follows on the main stream
+            self._run_on_side(encoder_weight_grads, st["dqkv"])
 
         # hproj feeds the encoder only (the quantiser branch is non-differentiable)
         if drop:

@@ -244,25 +244,32 @@ class WhisperForConditionalGeneration(KernelBlocks):
         else:
             self.ws.pop("w1pad", None)
         R, Rd = B * self.T, B * S
+        # decoder: the operands of the six weight gradients per layer live at a constant layer stride (one allocation per
+        # kind) - the saved activations xn1 / ctx / xn2 / ctxc / xn3 / g and the gradients dqkv / dyos / dqc / dyoc / dU /
+        # dyf each Dense layer receives - so that ONE batched GEMM per kind computes it for all layers after the decoder's
+        # backward loop (KernelBlocks._wgrad_batched; the encoder's layers are chip-sized GEMMs and keep their own launches)
+        for n, shp in (("xn1", (Rd, d)), ("ctx", (Rd, d)), ("xn2", (Rd, d)), ("ctxc", (Rd, d)), ("xn3", (Rd, d)), ("g", (Rd, ff)),
+                       ("dqkv", (Rd, 3 * d)), ("dyos", (Rd, d)), ("dqc", (Rd, d)), ("dyoc", (Rd, d)), ("dU", (Rd, ff)),
+                       ("dyf", (Rd, d))):
+            self._buf_layers("dec", cfg.decoder_layers, n, shp)
         for side, L, rows in (("enc", cfg.encoder_layers, R), ("dec", cfg.decoder_layers, Rd)):
             for i in range(L):
                 p = f"{side}{i}."
                 self._buf(p + "x_in", (rows, d))
-                self._buf(p + "xn1", (rows, d))
+                if side == "enc":
+                    self._buf(p + "xn1", (rows, d))
+                    self._buf(p + "ctx", (rows, d))
+                    self._buf(p + "xn2", (rows, d))
+                    self._buf(p + "g", (rows, ff))
                 self._buf(p + "qkv", (rows, 3 * d))
-                self._buf(p + "ctx", (rows, d))
                 self._buf(p + "x_mid", (rows, d))
-                self._buf(p + "xn2", (rows, d))
                 self._buf(p + "u", (rows, ff))
-                self._buf(p + "g", (rows, ff))
                 for s_ in ("ln1", "ln2"):
                     self._buf(p + s_ + ".mean", (rows,), f32)
                     self._buf(p + s_ + ".rstd", (rows,), f32)
                 if side == "dec":
                     self._buf(p + "x_mid2", (rows, d))
-                    self._buf(p + "xn3", (rows, d))
                     self._buf(p + "qc", (rows, d))
-                    self._buf(p + "ctxc", (rows, d))
                     self._buf(p + "ln3.mean", (rows,), f32)
                     self._buf(p + "ln3.rstd", (rows,), f32)
         self._buf("enc_x", (R, d))
@@ -545,17 +552,31 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # alternating buffers (a layer's weight gradient on the second stream may still be reading the other one)
         emit_on = os.environ.get("TMI_LN_EMIT", "1") != "0"
 
+        Ld = cfg.decoder_layers
+        # Decoder weight gradients deferred and batched over the layers (TMI_WGRAD_BATCH=0: one launch per layer, the round-2
+        # form): 24 launches of 13-26 us on B*S = 800 rows become 6 with L times the tiles (KernelBlocks._wgrad_batched).
+        batchd = os.environ.get("TMI_WGRAD_BATCH", "1") != "0" and Ld > 1
+
         def ffn_emit(side, i, rows):
             if not emit_on or i < 0:
                 return None
             pre = f"{'encoder' if side == 'enc' else 'decoder'}.layers.{i}.feed_forward.fc2.bias"
             site = (SITE_ENC_FFN if side == "enc" else SITE_DEC_FFN) + i
+            if side == "dec" and batchd:  # the per-layer buffer: masked copy (dropout) or snapshot (rate 0)
+                return (a.grad(pre), ws[f"dec{i}.dyf"], site)
             return (a.grad(pre), ws[f"dyd{i & 1}"][:rows] if drop else None, site)
 
-        def bias_emit(name):
-            return (a.grad(name), None, None) if emit_on else None
+        def bias_emit(name, snapshot=None):
+            """``snapshot``: per-layer buffer that receives a copy of the emitted dres (a deferred weight gradient's dy)."""
+            return (a.grad(name), snapshot, None) if emit_on else None
 
-        Ld = cfg.decoder_layers
+        def snap(buf, have):
+            """dres for a deferred reader: the LayerNorm backward wrote ``buf`` (``have``) or it is copied now."""
+            if not have:
+                self._guard_write(buf)
+                buf.copy_(dres)
+            return buf
+
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False, emit=ffn_emit("dec", Ld - 1, B * S))
         ready("decoder.layer_norm.gamma")
 
@@ -572,22 +593,33 @@ class WhisperForConditionalGeneration(KernelBlocks):
         for i in reversed(range(cfg.decoder_layers)):
             p, k = f"decoder.layers.{i}", f"dec{i}."
             Rd = B * S
-            dU, dt_, dctx, dqkv = ws["dU"][:Rd], ws["dtmp"][:Rd], ws["dctx"][:Rd], ws["dqkv"][:Rd]
+            dt_, dctx = ws["dtmp"][:Rd], ws["dctx"][:Rd]
+            dU = ws[k + "dU"] if batchd else ws["dU"][:Rd]
+            dqkv = ws[k + "dqkv"] if batchd else ws["dqkv"][:Rd]
+            wg = not batchd
             # FFN (with dropout the branch sees the masked gradient: the same mask, regenerated)
             dy = dres
-            if drop:
+            if batchd:
+                dy = ws[k + "dyf"]
+                if not emit_on:
+                    if drop:
+                        self._dropout(dres, dy, SITE_DEC_FFN + i)
+                    else:
+                        snap(dy, False)
+            elif drop:
                 dy = ws[f"dyd{i & 1}"][:Rd]
                 if not emit_on:
                     self._dropout(dres, dy, SITE_DEC_FFN + i)
-            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on)
-            self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_)
+            self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on, wgrad=wg)
+            self._dense_bwd(ws[k + "xn3"], dU, p + ".feed_forward.fc1.kernel", dt_, wgrad=wg)
             self._ln_bwd(dt_, ws[k + "x_mid2"], p + ".final_layer_norm", dres, k + "ln3", True,
-                         emit=bias_emit(p + ".encoder_attn.out_proj.bias"))
+                         emit=bias_emit(p + ".encoder_attn.out_proj.bias", ws[k + "dyoc"] if batchd else None))
             # cross attention: dK / dV feed only the shared k/v projections' backward after the loop, so their pass runs on the
             # second stream (its dO lives in a buffer of its own: the chain rewrites ws["dctx"] two kernels later)
             dctxc = ws[f"dctxc{i & 1}"][:Rd]
-            self._dense_bwd(ws[k + "ctxc"], dres, p + ".encoder_attn.out_proj.kernel", dctxc, bias_done=emit_on)
-            dqc = ws["dtmp"][:Rd]
+            dyoc = snap(ws[k + "dyoc"], emit_on) if batchd else dres
+            self._dense_bwd(ws[k + "ctxc"], dyoc, p + ".encoder_attn.out_proj.kernel", dctxc, bias_done=emit_on, wgrad=wg)
+            dqc = ws[k + "dqc"] if batchd else ws["dtmp"][:Rd]
             self._attn_bwd(k + ("statsc" if self.precision == "bf16" else "Pc"), (ws[k + "qc"], 0),
                            (kvc, 2 * i * d), (kvc, (2 * i + 1) * d), ws[k + "ctxc"], dctxc, (dqc, 0),
                            (dkv, 2 * i * d), (dkv, (2 * i + 1) * d), B, Hd, S, T, 0, site=SITE_DEC_CROSS + i,
@@ -605,17 +637,19 @@ class WhisperForConditionalGeneration(KernelBlocks):
                              accumulate=(i != cfg.decoder_layers - 1), a_off=lo, b_off=lo)
                 self._run_on_side(kv_backward, dkv[:, 2 * i * d:])
             dxn2 = ws["dctx"][:Rd]
-            self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2)
+            self._dense_bwd(ws[k + "xn2"], dqc, p + ".encoder_attn.q_proj.kernel", dxn2, wgrad=wg)
             self._ln_bwd(dxn2, ws[k + "x_mid"], p + ".encoder_attn_layer_norm", dres, k + "ln2", True,
-                         emit=bias_emit(p + ".self_attn.out_proj.bias"))
+                         emit=bias_emit(p + ".self_attn.out_proj.bias", ws[k + "dyos"] if batchd else None))
             # self attention
-            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on)
+            dyos = snap(ws[k + "dyos"], emit_on) if batchd else dres
+            self._dense_bwd(ws[k + "ctx"], dyos, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on, wgrad=wg)
             qkv = ws[k + "qkv"]
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, Hd, S, S, 1, site=SITE_DEC_SELF + i)
-            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
+            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_, wgrad=wg)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True, emit=ffn_emit("dec", i - 1, Rd))
-            ready(p + ".self_attn_layer_norm.gamma")
+            if not batchd:
+                ready(p + ".self_attn_layer_norm.gamma")
         if cfg.decoder_layers:
             if kv_per_layer:
                 self._main.wait_event(self._side_reads.pop(dkv.data_ptr()))  # d_enc is complete after layer 0's share
@@ -624,6 +658,22 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 # bias gradient and one dgrad (K = L*2d) for the cross-attention k/v projections of all layers
                 self._join_side()
                 self._dense_bwd(enc_out, dkv, "decoder.cross_kv.kernel", d_enc)
+            if batchd:
+                st = {n: ws[f"dec*.{n}"] for n in ("xn1", "ctx", "xn2", "ctxc", "xn3", "g", "dqkv", "dyos", "dqc", "dyoc", "dU", "dyf")}
+                lay = "decoder.layers.{}"
+
+                def decoder_weight_grads():
+                    nb = not emit_on  # the biases of the residual-stream layers come out of the LayerNorm backward otherwise
+                    self._wgrad_batched(st["g"], st["dyf"], lay + ".feed_forward.fc2.kernel", Ld, bias=nb)
+                    self._wgrad_batched(st["xn3"], st["dU"], lay + ".feed_forward.fc1.kernel", Ld)
+                    self._wgrad_batched(st["ctxc"], st["dyoc"], lay + ".encoder_attn.out_proj.kernel", Ld, bias=nb)
+                    self._wgrad_batched(st["xn2"], st["dqc"], lay + ".encoder_attn.q_proj.kernel", Ld)
+                    self._wgrad_batched(st["ctx"], st["dyos"], lay + ".self_attn.out_proj.kernel", Ld, bias=nb)
+                    self._wgrad_batched(st["xn1"], st["dqkv"], lay + ".self_attn.qkv.kernel", Ld)
+                # on the second stream, under the start of the encoder's backward
+                self._run_on_side(decoder_weight_grads, st["dqkv"])
+                for i in reversed(range(Ld)):
+                    ready(f"decoder.layers.{i}.self_attn_layer_norm.gamma")
             ready("decoder.cross_kv.kernel")
         # the embedding's backward (mask of W:411, scatter of the rows) feeds nothing on the chain: second stream
         gemb, dres_dec = a.grad("decoder.embed_tokens.embeddings"), dres
