@@ -806,8 +806,15 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   P.part = reinterpret_cast<float*>(dp->workspace);
   dim3 grid((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  static const int focc = [] { const char* e = getenv("TMI_ATTN_FWD_OCC"); return e ? atoi(e) : 0; }();
   if (P.drop_thr) {
-    hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
+    if (focc == 4) hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (focc == 5) hipLaunchKernelGGL((attn_fwd_kernel<true, 5>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (focc == 2) hipLaunchKernelGGL((attn_fwd_kernel<true, 2>), grid, dim3(256), 4 * IMG, hs, P);
+    else hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
+  } else if (focc == 4 || focc == 5) {
+    if (focc == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), grid, dim3(256), 4 * IMG, hs, P);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, 5>), grid, dim3(256), 4 * IMG, hs, P);
   } else {
     static const int abl = [] { const char* e = getenv("TMI_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 1>), grid, dim3(256), 4 * IMG, hs, P);
@@ -847,9 +854,16 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.part = reinterpret_cast<float*>(dp->workspace);
   if (do_dq) {
   dim3 gq((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
-  if (P.drop_thr)
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
-  else
+  static const int qocc = [] { const char* e = getenv("TMI_ATTN_DQ_OCC"); return e ? atoi(e) : 0; }();
+  if (P.drop_thr) {
+    if (qocc == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 3>), gq, dim3(256), 4 * IMG, s, P);
+    else if (qocc == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 4>), gq, dim3(256), 4 * IMG, s, P);
+    else if (qocc == 5) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 5>), gq, dim3(256), 4 * IMG, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
+  } else if (qocc == 4 || qocc == 5) {
+    if (qocc == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 4>), gq, dim3(256), 4 * IMG, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 5>), gq, dim3(256), 4 * IMG, s, P);
+  } else
     hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 3>), gq, dim3(256), 4 * IMG, s, P);
   if (P.ksplit > 1) {
     const int64_t rows = dp->B * dp->H * dp->Tq;
@@ -863,9 +877,16 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   if (!do_dkv) return TMI_OK;
   P.ksplit = 1;
   dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
-  if (P.drop_thr)
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
-  else
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, dim3(256), 4 * IMG + 2 * NCONST * 64 * sizeof(float), s, P);
+  static const int kocc = [] { const char* e = getenv("TMI_ATTN_DKV_OCC"); return e ? atoi(e) : 0; }();
+  const size_t klds = 4 * IMG + 2 * NCONST * 64 * sizeof(float);
+  if (P.drop_thr) {
+    if (kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 3>), gk, dim3(256), klds, s, P);
+    else if (kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 4>), gk, dim3(256), klds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), klds, s, P);
+  } else {
+    if (kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 3>), gk, dim3(256), klds, s, P);
+    else if (kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 4>), gk, dim3(256), klds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, dim3(256), klds, s, P);
+  }
   return tmi_check_launch("tmi_attn_bwd(dkv)");
 }

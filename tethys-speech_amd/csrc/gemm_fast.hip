@@ -1184,7 +1184,9 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
     if (d.splitk == 0 && d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0 && !d.bias && !d.act &&
         !d.aux_out && !d.aux_in && !d.resid && d.scale_cols <= 0) {
       const int64_t wgs = (int64_t)8 * P.ptm * P.ptn * d.nbatch;
-      static const int cap = [] { const char* e = getenv("TMI_GEMM_P8_MAXSPLIT"); return e ? atoi(e) : 8; }();
+      // (cap 4, round 3: measured in the step - the weight gradients run beside the dgrad chain, where a split costs slab
+      // traffic and CUs the other stream could use: 8.82 -> 8.74 ms/step against a cap of 8; 2 and 1 lose)
+      static const int cap = [] { const char* e = getenv("TMI_GEMM_P8_MAXSPLIT"); return e ? atoi(e) : 4; }();
       int64_t want = 256 / wgs;
       if (want > P.ktiles / 6) want = P.ktiles / 6;
       if (want > cap) want = cap;
@@ -1272,7 +1274,10 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
       // short K with heavy epilogues / k-strided weights (TMI_GEMM_P8_192_SHORTK=1, off): alone and with a plain epilogue the
       // 192-row tile wins there too (fc1 forward 12000 x 3072 x 768: 100.6 -> 80.3 us), but with the real GELU + aux epilogues
       // in the step the one-workgroup-per-CU kernel loses to two co-resident 128x128 workgroups: 9.06 -> 9.29 ms/step
-      if (win192 && (long_k || short192)) return launch_p8<TC, false, B_KS, 192>(d, stream);
+      // (=2: only the forward fc1 shape - GELU + saved pre-activation, no aux_in - which runs alone on the chip: the forward
+      // pass has no second stream beside it, so what counts there is the launch's own latency)
+      const bool fwd_only = short192 == 2 && d.act == 1 && !d.aux_in;
+      if (win192 && (long_k || short192 == 1 || fwd_only)) return launch_p8<TC, false, B_KS, 192>(d, stream);
       if (long_k) return launch_p8<TC, false, B_KS>(d, stream);
     }
   }

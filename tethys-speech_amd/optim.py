@@ -29,13 +29,45 @@ class Adam:
 
     def apply_gradients(self, model, strategy=None, grad_scale=1.0, zero_grad=False):
         """``zero_grad``: the kernel leaves the gradient arena zeroed (``arena.g_clean``), so the next
-        ``forward_backward`` skips its fill pass; callers that still want to look at the gradients pass False."""
+        ``forward_backward`` skips its fill pass; callers that still want to look at the gradients pass False.
+        After ``begin_early`` only the ranges no early slice has updated are left to do (same step count)."""
         a = model.arena
         if strategy is not None:
             strategy.all_reduce_gradients(a.g)
-        self.iterations += 1
-        self._update(model, 0, a.numel, grad_scale, zero_grad, 0)
+        early, self._early = self.__dict__.get("_early"), None
+        if early is None:
+            self.iterations += 1
+            self._update(model, 0, a.numel, grad_scale, zero_grad, 0)
+        else:
+            if not zero_grad:
+                raise ValueError("early Adam slices zero their gradients: finish the step with zero_grad=True")
+            pos = 0
+            for lo, hi in sorted(early):
+                if lo > pos:
+                    self._update(model, pos, lo, grad_scale, zero_grad, 0)
+                pos = max(pos, hi)
+            if pos < a.numel:
+                self._update(model, pos, a.numel, grad_scale, zero_grad, 0)
         a.g_clean = bool(zero_grad)
+
+    def begin_early(self, model, grad_scale=1.0):
+        """Start this step's update before backward has finished: returns ``update(lo, hi)``, which runs Adam on the arena
+        range [lo, hi) NOW, on whatever stream ``ops`` is pinned to (the caller orders it after the last writer of those
+        gradients and the last reader of those weights); ``apply_gradients`` then does the rest.  Whisper uses it for the
+        LM head and the embedding table (54 % of the small-ref parameters): their gradients are final at the very start /
+        end of the decoder's backward - a chain of decoder-sized kernels that leaves the chip idle - so their share of the
+        4.4 GB Adam stream runs on the second stream under it instead of alone at the end of the step.  Per-parameter
+        arithmetic is unchanged (Adam is elementwise): the result is bit for bit the single-launch update."""
+        self.iterations += 1
+        self._early = []
+        blocks = self.EARLY_BLOCKS  # a throttled grid: the full-width kernel saturates HBM and starves the chain it runs under
+
+        def update(lo, hi):
+            self._update(model, lo, hi, grad_scale, True, blocks)
+            self._early.append((lo, hi))
+        return update
+
+    EARLY_BLOCKS = int(os.environ.get("TMI_ADAM_EARLY_BLOCKS", "256"))
 
     def _update(self, model, lo, hi, grad_scale, zero_grad, max_blocks):
         """Adam over arena range [lo, hi).  The parts of it that are embedding tables (``model.embedding_tables()``:

@@ -18,6 +18,10 @@ from .whisper import create_whisper_model
 # ms/step for grids of 16-512 workgroups).  What it does buy everywhere is the zeroing of the gradient arena inside
 # the Adam kernel instead of a separate fill pass.
 ADAM_UNDER_BACKWARD = os.environ.get("TMI_ADAM_UNDER_BACKWARD", "0") != "0"
+# What does pay (round 3): only the slices whose gradients are final while the chip is idle anyway - the LM head and the
+# embedding table under the decoder's backward chain (optim.Adam.begin_early).  One replica only: with replicas the
+# gradients have to be exchanged first.  TMI_ADAM_EARLY=0 restores the single update at the end of the step.
+ADAM_EARLY = os.environ.get("TMI_ADAM_EARLY", "1") != "0"
 
 
 def distributed_train_step(strategy, model, dist_inputs, optimizer):
@@ -32,8 +36,12 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
     overlapped = ADAM_UNDER_BACKWARD and model.device.type == "cuda"
     if overlapped:  # Adam slice by slice as buckets become final (and reduced), under the rest of backward
         optimizer.begin_overlapped(model, strategy)
+    early = None
+    if (ADAM_EARLY and not overlapped and not strategy._collective and model.device.type == "cuda" and features.shape[0] > 0
+            and model._side is not None):
+        early = optimizer.begin_early(model)
     if features.shape[0] > 0:
-        loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready)
+        loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready, early_update=early)
     else:
         # same reports as a real backward, so this rank's bucket launches match its peers' one for one
         model.report_zero_gradients(strategy.gradients_ready)

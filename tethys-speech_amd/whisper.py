@@ -365,24 +365,27 @@ class WhisperForConditionalGeneration(KernelBlocks):
 
     # -- forward -------------------------------------------------------------------------
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
-                         grad_ready=None):
+                         grad_ready=None, early_update=None):
         """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
         ``_forward_backward``."""
         self.begin_step()
         try:
-            return self._forward_backward(features, labels, loss_scale, grad_ready)
+            return self._forward_backward(features, labels, loss_scale, grad_ready, early_update)
         finally:
             self.end_step()
             self._drop_step += 1  # next step draws fresh masks
 
     def _forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
-                         grad_ready=None):
+                         grad_ready=None, early_update=None):
         """One replica's forward + backward (W:826-833).  features [B, n_mels, T_in] fp32,
         labels [B, S] int32, both on the device.  Gradients land in ``arena.g`` (which is
         zeroed first); returns the device scalar loss (mean over B*(S-1), W:600).
         ``grad_ready(lo, hi)`` is called during backward each time the gradients of the arena
         range [lo, hi) are final, last range first (the data-parallel strategy all-reduces them
-        under the rest of backward)."""
+        under the rest of backward).  ``early_update(lo, hi)`` (optim.Adam.begin_early, one replica): the optimizer
+        update of an arena range, called on the second stream as soon as that range's gradients are final and its
+        weights have been read for the last time in this step - the LM head and the embedding table, under the
+        decoder's backward chain."""
         cfg = self.config
         B, Cn, T_in = features.shape
         S = labels.shape[1]
@@ -535,7 +538,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # ================= backward =================
         dres = ws["dres_dec"]
         dW = a.grad("lm_head.kernel")
-        ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp, splitk=0)
+        # the LM head's weight gradient (K = B*S rows against a [d, 51904] output: 120 us) feeds nothing on the chain: second
+        # stream, under the decoder's backward (a chain of decoder-sized kernels on a mostly idle chip)
+        self._run_on_side(lambda: ops.gemm(ws["dec_out"], logits, dW, d, Vp, B * S, 1, d, Vp, 1, Vp, splitk=0), logits)
         dtmp = ws["dtmp"][:B * S]
         # dgrad over the padded vocab (pad columns of dlogits are zero): a whole number of K tiles
         # (K = 51904 against only B*S x d outputs: in bf16 mode reduce it split-K into fp32 and round once)
@@ -546,6 +551,12 @@ class WhisperForConditionalGeneration(KernelBlocks):
             ops.cast_bf16(acc, d, dtmp, d, B * S, d)
         else:
             ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
+        if early_update is not None:
+            # lm_head: gradient final (weight gradient above, same stream), weights read for the last time by the dgrad just
+            # enqueued on the main stream (the event _run_on_side records here orders the update behind it)
+            lm_lo = a.offsets["lm_head.kernel"]
+            # (keyed by a buffer nothing in backward rewrites: a _guard_write on the key would make the chain wait for Adam)
+            self._run_on_side(lambda: early_update(lm_lo, a.numel), ws["row_loss"])
         # Column sums (bias gradients) and Dropout-masked copies of the residual-stream gradient come out of the LayerNorm
         # backward that produces it (tmi_layernorm_bwd_emit): ffn_emit(side, i) = what layer i's fc2 needs of the dres
         # handed down to it - its bias gradient and, with dropout, dres under the mask of W:205 in one of two
@@ -682,6 +693,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
             if drop:
                 ops.dropout(dres_dec, dres_dec, dres_dec.shape[0], dres_dec.shape[1], self._drop_p, self._site_seed(SITE_DEC_EMBED))
             ops.embed_bwd(labels, dres_dec, gemb, B, S, d, cfg.decoder_start_token_id)
+            if early_update is not None:  # the table's gradient is final; its forward read happened long ago
+                e_lo = a.offsets["decoder.embed_tokens.embeddings"]
+                early_update(e_lo, e_lo + gemb.numel())
         self._run_on_side(embed_backward, dres_dec)
         ready("decoder.embed_tokens.embeddings")
 
