@@ -175,11 +175,19 @@ class KernelBlocks:
             ops.set_stream(self._prev_override)
             self._main = None
 
+    # Number of weight-gradient streams ("lanes"; TMI_WGRAD_LANES).  Round 3 tried two - a layer's weight gradients are
+    # independent, so two side by side could each run with a smaller split-K (fewer workgroups, longer K loops, less slab
+    # traffic) - and measured it level with one (8.58 = 8.58 ms/step at a split cap of 4; smaller caps lose with either:
+    # the no-split kernel needs 1.36 us per K-tile, the per-CU staging rate, not the MFMA's 0.86).  One stays the default.
+    N_LANES = max(1, int(os.environ.get("TMI_WGRAD_LANES", "1")))
+
     def enable_wgrad_stream(self, on=True):
         on = on and self.device.type == "cuda"
-        self._side = torch.cuda.Stream(device=self.device) if on else None
-        self._side_handle = self._side.cuda_stream if on else None
-        self._side_reads = {}
+        self._sides = [torch.cuda.Stream(device=self.device) for _ in range(self.N_LANES)] if on else []
+        self._side = self._sides[0] if on else None           # lane 0: also the stream of the non-GEMM side work
+        self._side_handles = [st.cuda_stream for st in self._sides]
+        self._side_handle = self._side_handles[0] if on else None
+        self._side_reads = {}     # buffer address -> {lane: event recorded after the lane's last reader of it}
         self._done_events = {}
         # events are reused round-robin: creating two per launch costs more host time than the
         # decoder-sized kernels take (re-recording an event other work already waited on is legal)
@@ -192,67 +200,78 @@ class KernelBlocks:
         self._ev_i = (self._ev_i + 1) % len(self._ev_ring)
         return ev
 
-    def _run_on_side(self, fn, dy, defer=False, ready=None):
+    def _run_on_side(self, fn, dy, defer=False, ready=None, lane=0):
         """Launch ``fn``'s kernels (readers of the finished buffer ``dy``, writers of gradients only)
-        on the weight-gradient stream, or inline if there is none.  ``defer`` (TMI_DEFER_WGRAD=1): do not enqueue yet -
-        ``_flush_deferred`` does, at the point the caller picks (before a kernel the work should run beside)."""
+        on a weight-gradient stream (``lane``), or inline if there is none.  ``defer`` (TMI_DEFER_WGRAD=1): do not enqueue
+        yet - ``_flush_deferred`` does, at the point the caller picks (before a kernel the work should run beside)."""
         if self._side is None:
             fn()
             return
+        lane = lane % len(self._sides)
         if ready is None:
             # a ring slot is only good for an event that is waited for at once; one that is parked (TMI_DEFER_WGRAD)
             # could be re-recorded by a later launch before its waiter is enqueued, so it gets an event of its own
             ready = torch.cuda.Event() if (defer and _DEFER_WGRAD) else self._event()
             ready.record(self._main or torch.cuda.current_stream())  # dy is complete on the main stream here
         if defer and _DEFER_WGRAD:
-            self.__dict__.setdefault("_deferred", []).append((fn, dy, ready))
+            self.__dict__.setdefault("_deferred", []).append((fn, dy, ready, lane))
             return
-        self._side.wait_event(ready)
-        prev = ops.set_stream(self._side_handle)
+        side = self._sides[lane]
+        side.wait_event(ready)
+        prev = ops.set_stream(self._side_handles[lane])
         try:
             fn()
         finally:
             ops.set_stream(prev)
         # "done" events are STORED (``_side_reads``) and waited for arbitrarily later - decoder buffers two layers on,
-        # the early-decoder / kv_rest / embedding hand-offs - so they never come from the ring: one event per buffer
-        # address, re-recorded only by a later reader of the same buffer on the same (side) stream, which supersedes it
+        # the early-decoder / kv_rest / embedding hand-offs - so they never come from the ring: one event per (buffer
+        # address, lane), re-recorded only by a later reader of the same buffer on the same stream, which supersedes it
         key = dy.data_ptr()
-        done = self._done_events.get(key)
+        done = self._done_events.get((key, lane))
         if done is None:
-            done = self._done_events[key] = torch.cuda.Event()
-        done.record(self._side)
-        self._side_reads[key] = done
+            done = self._done_events[(key, lane)] = torch.cuda.Event()
+        done.record(side)
+        self._side_reads.setdefault(key, {})[lane] = done
 
     def _flush_deferred(self):
         pend = self.__dict__.get("_deferred")
         if pend:
             self._deferred = []
-            for fn, dy, ready in pend:
-                self._run_on_side(fn, dy, ready=ready)
+            for fn, dy, ready, lane in pend:
+                self._run_on_side(fn, dy, ready=ready, lane=lane)
+
+    def _pop_side_reads(self, tensor):
+        """Events after which every queued side-stream reader of ``tensor`` has finished (and forget them)."""
+        return list(self._side_reads.pop(tensor.data_ptr(), {}).values())
+
+    def _wait_events(self, events):
+        main = self._main or torch.cuda.current_stream()
+        for ev in events:
+            main.wait_event(ev)
 
     def _guard_write(self, *tensors):
         if self._side is None:
             return
         pend = self.__dict__.get("_deferred")
-        if pend and any(t.data_ptr() == dy.data_ptr() for t in tensors for _, dy, _ in pend):
+        if pend and any(t.data_ptr() == dy.data_ptr() for t in tensors for _, dy, _, _ in pend):
             self._flush_deferred()  # a queued-but-not-enqueued reader of this buffer: enqueue it, then wait for it below
         if not self._side_reads:
             return
         for t in tensors:
-            ev = self._side_reads.pop(t.data_ptr(), None)
-            if ev is not None:
-                (self._main or torch.cuda.current_stream()).wait_event(ev)
+            self._wait_events(self._pop_side_reads(t))
 
     def gradient_streams(self):
         """Streams other than the compute stream on which gradient-producing kernels are queued."""
         self._flush_deferred()
-        return [self._side] if self._side is not None else []
+        return list(self._sides) if self._side is not None else []
 
     def _join_side(self):
-        """Main stream waits for everything queued on the weight-gradient stream."""
+        """Main stream waits for everything queued on the weight-gradient streams."""
         self._flush_deferred()
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = torch.cuda.current_stream()
+            for st in self._sides:
+                cur.wait_stream(st)
             self._side_reads.clear()
 
     def refresh_shadows(self):
@@ -351,7 +370,7 @@ class KernelBlocks:
                       bias=bias, **epi)
 
     def _dense_bwd(self, x2d, dy2d, wname, dx2d=None, accumulate_dx=False, aux_in=None, dgrad_on_side=False,
-                   dgrad_epi=None, bias_done=False, defer=False, wgrad=True):
+                   dgrad_epi=None, bias_done=False, defer=False, wgrad=True, lane=0):
         """dW = xᵀ·dy, db = colsum(dy), optionally dx (=|+=) dy·Wᵀ (* gelu'(aux_in)).
         ``dgrad_on_side``: dx is not needed by the chain that follows (the caller joins the side stream
         before its consumer), so the dgrad goes to the weight-gradient stream too."""
@@ -377,7 +396,7 @@ class KernelBlocks:
             self._run_on_side(lambda: (weight_grads(), dgrad()), dy2d)
             return
         if wgrad:  # (False: the caller batches this layer's weight gradient with the other layers', _wgrad_batched)
-            self._run_on_side(weight_grads, dy2d, defer=defer)
+            self._run_on_side(weight_grads, dy2d, defer=defer, lane=lane)
         if dx2d is not None:
             self._guard_write(dx2d)
             dgrad()

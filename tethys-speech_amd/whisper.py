@@ -460,7 +460,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         early_ev = None
         if early_dec:
             self._run_on_side(lambda: (dec_embed(), dec_self_block(0)), labels)
-            early_ev = self._side_reads.pop(labels.data_ptr())
+            early_ev = self._pop_side_reads(labels)
         # ---- encoder stem (W:329-339)
         xp0, h1pad, u1pad = ws["xp0"], ws["h1pad"], ws["u1pad"]
         ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
@@ -511,7 +511,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc, n_off=0, n_cols=2 * d)
                 self._run_on_side(lambda: self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc[:, 2 * d:], n_off=2 * d,
                                                           n_cols=(Ld - 1) * 2 * d), enc_out)
-                kv_rest = self._side_reads.pop(enc_out.data_ptr())
+                kv_rest = self._pop_side_reads(enc_out)
             else:
                 self._dense_fwd(enc_out, "decoder.cross_kv.kernel", kvc)
                 kv_rest = None
@@ -519,9 +519,9 @@ class WhisperForConditionalGeneration(KernelBlocks):
             if not (early_dec and i == 0):
                 dec_self_block(i)
             elif early_ev is not None:
-                self._main.wait_event(early_ev)  # layer 0's self-attention block ran beside the encoder
+                self._wait_events(early_ev)  # layer 0's self-attention block ran beside the encoder
             if i == 1 and kv_rest is not None:
-                self._main.wait_event(kv_rest)
+                self._wait_events(kv_rest)
             dec_cross_ffn(i)
         self._ln_fwd(ws["dec_x"], "decoder.layer_norm", ws["dec_out"], "dec_ln")
 
@@ -663,7 +663,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 ready(p + ".self_attn_layer_norm.gamma")
         if cfg.decoder_layers:
             if kv_per_layer:
-                self._main.wait_event(self._side_reads.pop(dkv.data_ptr()))  # d_enc is complete after layer 0's share
+                self._wait_events(self._pop_side_reads(dkv))  # d_enc is complete after layer 0's share
             else:
                 # every layer's dk / dv is in place (their passes ran on the second stream: join it): one weight gradient, one
                 # bias gradient and one dgrad (K = L*2d) for the cross-attention k/v projections of all layers
@@ -717,17 +717,18 @@ class WhisperForConditionalGeneration(KernelBlocks):
                     self._dropout(dres, dy, SITE_ENC_FFN + i)
             # (TMI_DEFER_WGRAD=1: the two FFN weight gradients are enqueued when the attention backward starts - MFMA-bound work
             # beside the VALU-bound attention kernels instead of beside the FFN dgrads)
+            # (the four weight gradients of a layer alternate between the two weight-gradient streams: KernelBlocks.N_LANES)
             self._dense_bwd(ws[k + "g"], dy, p + ".feed_forward.fc2.kernel", dU, aux_in=ws[k + "u"], bias_done=emit_on,
-                            defer=dy is not dres)
-            self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_, defer=True)
+                            defer=dy is not dres, lane=0)
+            self._dense_bwd(ws[k + "xn2"], dU, p + ".feed_forward.fc1.kernel", dt_, defer=True, lane=1)
             self._ln_bwd(dt_, ws[k + "x_mid"], p + ".final_layer_norm", dres, k + "ln2", True,
                          emit=bias_emit(p + ".self_attn.out_proj.bias"))
-            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on)
+            self._dense_bwd(ws[k + "ctx"], dres, p + ".self_attn.out_proj.kernel", dctx, bias_done=emit_on, lane=0)
             qkv = ws[k + "qkv"]
             self._flush_deferred()
             self._attn_bwd(k + ("stats" if self.precision == "bf16" else "P"), (qkv, 0), (qkv, d), (qkv, 2 * d),
                            ws[k + "ctx"], dctx, (dqkv, 0), (dqkv, d), (dqkv, 2 * d), B, He, T, T, 0, site=SITE_ENC_ATTN + i)
-            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_)
+            self._dense_bwd(ws[k + "xn1"], dqkv, p + ".self_attn.qkv.kernel", dt_, lane=1)
             self._ln_bwd(dt_, ws[k + "x_in"], p + ".self_attn_layer_norm", dres, k + "ln1", True, emit=ffn_emit("enc", i - 1, R))
             ready(p + ".self_attn_layer_norm.gamma")
 
