@@ -68,11 +68,32 @@ def host_cpu():
         avail = len(os.sched_getaffinity(0))
     except Exception:
         avail = os.cpu_count() or 1
-    # "all physical cores of one socket" (and 5, the reference pod's limit).  TMI_BENCH_CPU_SHARE
-    # caps it for a box whose cgroup share is smaller than its affinity mask says (unset: no cap)
-    share = int(os.environ.get("TMI_BENCH_CPU_SHARE", "0")) or (per_socket or avail)
+    # "all physical cores of one socket" (and 5, the reference pod's limit) - of the cores this
+    # process may actually USE: a container's CPU quota (cgroup cpu.max / cfs_quota) is honoured, because threads beyond it
+    # only time-slice (measured on a 16-core share of a 64-core EPYC 9575F: 9-11 s/step on 16 threads, 15.8 s/step on 64).
+    # TMI_BENCH_CPU_SHARE overrides the quota (0 / unset: read it from the cgroup).
+    share = int(os.environ.get("TMI_BENCH_CPU_SHARE", "0")) or cgroup_cpu_quota() or (per_socket or avail)
     threads = max(1, min(avail, per_socket or avail, share))
     return model, threads, avail
+
+
+def cgroup_cpu_quota():
+    """CPUs this process's cgroup may use (ceil of quota / period), or 0 when there is no quota."""
+    import math
+    try:  # cgroup v2
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, math.ceil(int(q) / int(p)))
+    except Exception:
+        pass
+    try:  # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and p > 0:
+            return max(1, math.ceil(q / p))
+    except Exception:
+        pass
+    return 0
 
 
 def _time_oracle(run_steps, threads, warm, timed):
@@ -136,11 +157,18 @@ def cpu_baseline_whisper(model_type, batch, dev, budget_s):
         m.arena.load_ref(params0)
         opt = optim.Adam(learning_rate=1e-4)
         strat = D.DataParallelStrategy(0, 1)
-        gl = [float(train.distributed_train_step(strat, m, (torch.from_numpy(np.ascontiguousarray(f)).to(dev),
-                                                            torch.from_numpy(np.ascontiguousarray(l)).to(dev)), opt).item())
-              for f, l in used]
+        dev_batches = [(torch.from_numpy(np.ascontiguousarray(f)).to(dev), torch.from_numpy(np.ascontiguousarray(l)).to(dev))
+                       for f, l in used]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gl_t = [train.distributed_train_step(strat, m, b_, opt).clone() for b_ in dev_batches]
+        torch.cuda.synchronize()
+        fp32_ms = (time.perf_counter() - t0) / len(dev_batches) * 1e3  # (the first step includes the workspace set-up)
+        gl = [float(t.item()) for t in gl_t]
         diff = max(abs(a - b) for a, b in zip(gl, cpu_losses))
-        check.update({"gpu_fp32_losses": gl, "max_abs_diff": diff, "agree": diff <= 1e-3})
+        check.update({"gpu_fp32_losses": gl, "max_abs_diff": diff, "agree": diff <= 1e-3,
+                      "gpu_fp32_ms_per_step": fp32_ms,
+                      "gpu_fp32_note": "the parity mode (exact-fp32 MFMA, scores materialised as the reference does), timed over these steps"})
         log(f"loss cross-check CPU oracle fp32 vs GPU fp32 over {len(gl)} steps: max |d| = {diff:.2e}")
         del m
         torch.cuda.empty_cache()
@@ -150,10 +178,11 @@ def cpu_baseline_whisper(model_type, batch, dev, budget_s):
     return {"value": clip * batch / s1, "unit": "audio-seconds/sec", "cores": threads, "kind": "port",
             "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, whisper-{model_type}-ref, batch {batch}, "
                       f"30 s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads "
-                      f"(all physical cores of one socket; {CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
-            "cpu_model": cpu_model, "nproc": nproc,
+                      f"(the physical cores of one socket this process may use: cgroup quota {cgroup_cpu_quota() or 'none'}; "
+                      f"{CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
+            "cpu_model": cpu_model, "nproc": nproc, "cgroup_cpu_quota": cgroup_cpu_quota(),
             "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1,
-                          "note": "all physical cores of one socket (BASELINE.md 3.3)"},
+                          "note": "all physical cores of one socket this process may use (BASELINE.md 3.3; cgroup quota honoured)"},
                          {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": CPU_TIMED_MIN,
                           "note": "the reference pod's CPU limit (sample_tfjobs/whisper-dist.yaml:36)"}],
             "loss_check": check}
@@ -229,10 +258,11 @@ def cpu_baseline_w2v(size, batch, dev, budget_s, single=False):
             "sample": f"restated reference CPU path (TensorFlow unavailable): oracle fp32, wav2vec2-{size} pre-training step "
                       f"({'S: whisper_single.py' if single else 'V:'}), "
                       f"batch {batch}, {clip:g} s clips, pool seed 1234, 1 warm-up + {n1} timed steps, {s1:.2f} s/step on {threads} threads "
-                      f"(all physical cores of one socket; {CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
-            "cpu_model": cpu_model, "nproc": nproc,
+                      f"(the physical cores of one socket this process may use: cgroup quota {cgroup_cpu_quota() or 'none'}; "
+                      f"{CPU_TIMED_MIN} more timed steps on {min(POD_CPU_LIMIT, nproc)} threads: {s5:.2f} s/step)",
+            "cpu_model": cpu_model, "nproc": nproc, "cgroup_cpu_quota": cgroup_cpu_quota(),
             "settings": [{"threads": threads, "s_per_step": s1, "value": clip * batch / s1, "timed_steps": n1,
-                          "note": "all physical cores of one socket (BASELINE.md 3.3)"},
+                          "note": "all physical cores of one socket this process may use (BASELINE.md 3.3; cgroup quota honoured)"},
                          {"threads": min(POD_CPU_LIMIT, nproc), "s_per_step": s5, "value": clip * batch / s5, "timed_steps": CPU_TIMED_MIN,
                           "note": "the reference pod's CPU limit (sample_tfjobs/wav2vec2-dist.yaml)"}],
             "loss_check": check}
@@ -276,7 +306,8 @@ def measure_roofline(model, one_step, nprof, precision, tag):
     # same command (tools/pmc_traffic.py), bytes per tmi_gemm launch.  FETCH_SIZE / WRITE_SIZE are the L2's fabric-side
     # counters (Infinity-Cache hits included, guide section HBM), FETCH_SIZE doubled per the gfx950 note.
     traffic, traffic_src = None, None
-    for name in (f"r02_{tag}_gemm_pmc_traffic.json", f"r01_{tag}_gemm_pmc_traffic.json" if tag != "whisper" else "r01_gemm_pmc_traffic.json"):
+    for name in (f"r03_{tag}_gemm_pmc_traffic.json", f"r02_{tag}_gemm_pmc_traffic.json",
+                 f"r01_{tag}_gemm_pmc_traffic.json" if tag != "whisper" else "r01_gemm_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)

@@ -337,7 +337,11 @@ def _bench_worker(rank, world, port, q):
         return torch.tensor([float(rank)])
     args = types.SimpleNamespace(steps=5, warmup=2)
     dt, last, host_ms = bench.timed_region(one_step, args, strat, "cpu", world)
-    q.put((rank, dt, torch.stack(seen).numpy(), bench.throughput(30.0, 4, world, args.steps, dt)))
+    nseen = len(seen)
+    # the N > 1 diagnostics of the bench line (VERDICT r2 item 5 ii): every rank calls it, collectives inside
+    diag = bench.exchange_diagnostics(one_step, args, strat, "cpu", world, dt / args.steps * 1e3, host_ms)
+    assert strat.exchange_off is False
+    q.put((rank, dt, torch.stack(seen[:nseen]).numpy(), bench.throughput(30.0, 4, world, args.steps, dt), diag))
     dist.destroy_process_group()
 
 
@@ -354,8 +358,13 @@ def test_bench_timing_logic_two_rank_gloo():
     res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
     for p_ in procs:
         p_.join(60)
-    (_, dt0, seen0, v0), (_, dt1, seen1, v1) = res
+    (_, dt0, seen0, v0, diag0), (_, dt1, seen1, v1, diag1) = res
     assert dt0 == dt1 and v0 == v1
+    for dg in (diag0, diag1):
+        assert dg["rccl_ranks"] == 2 and dg["backend"] == "gloo" and len(dg["host_enqueue_ms"]) == 2
+        # the stand-in step has no exchange: with and without it the slow rank's 50 ms per step
+        assert abs(dg["exposed_exchange_ms"]) < 15.0 and 45.0 < dg["ms_per_step_without_exchange"] < 70.0
+    assert diag0["host_enqueue_ms"] == diag1["host_enqueue_ms"] and diag0["host_enqueue_ms"][1] > diag0["host_enqueue_ms"][0]
     assert dt0 >= 5 * 0.05 and dt0 < 5 * 0.05 + 0.5        # the slow rank's 5 timed steps, not the fast rank's
     assert v0 == pytest.approx(30.0 * 4 * 2 * 5 / dt0)
     f, _ = O.create_dummy_pool(seed=1234, n_mels=4, seq_len=16)

@@ -6,10 +6,13 @@ tr = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(tr))))
 # a step ends with its LAST optimizer launch (the update may be several launches: dense ranges, the row-sparse
 # embedding table, or the segmented Adam-with-clipping): consecutive Adam launches with nothing between them are one
-adam_all = [i for i, r in enumerate(rows) if "adam_" in r[2] and "kernel" in r[2]]
-adam = [i for k, i in enumerate(adam_all) if k + 1 == len(adam_all) or adam_all[k + 1] != i + 1]
+# (round 3: early Adam slices run inside backward, so optimizer launches no longer delimit steps: a step STARTS with the
+# input transpose of Whisper (feat_cl_kernel) or the FIR filter bank of Wav2Vec2; the last step ends with its last Adam)
+starts = [i for i, r in enumerate(rows) if "feat_cl_kernel" in r[2] or ("fir_gn_partial" in r[2])]
+starts = [i for k_, i in enumerate(starts) if k_ == 0 or rows[i][0] - rows[starts[k_ - 1]][0] > 1_000_000]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-lo, hi = adam[-nsteps - 1] + 1, adam[-1] + 1
+nsteps = min(nsteps, len(starts) - 1)
+lo, hi = starts[-nsteps - 1], starts[-1]
 seg = rows[lo:hi]
 t0, t1 = seg[0][0], max(r[1] for r in seg)
 busy = 0; cur_s, cur_e = seg[0][0], seg[0][1]; gaps = []

@@ -22,7 +22,7 @@ for r in R:
 rows.sort()
 # a step starts with the input transpose (Whisper: feat_cl_kernel) or the FIR filter bank (Wav2Vec2); optimizer launches
 # may sit anywhere inside a step (early Adam slices), so they are no delimiter
-starts = [i for i, r in enumerate(rows) if "feat_cl_kernel" in r[2] or "fir_gn_stats" in r[2] or "fir_groupnorm" in r[2]]
+starts = [i for i, r in enumerate(rows) if "feat_cl_kernel" in r[2] or ("fir_gn_partial" in r[2])]
 starts = [i for k_, i in enumerate(starts) if k_ == 0 or rows[i][0] - rows[starts[k_ - 1]][0] > 1_000_000]
 k = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else 1
 lo, hi = starts[-k - 1], starts[-k]
