@@ -449,6 +449,16 @@ template <> struct Cfg<10> { static constexpr int BM = 64, BN = 64, WM = 32, WN 
 template <> struct Cfg<11> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 2; static constexpr bool SPEC = false; };
 // CFG 12: CFG 11 with the 4-stage ring of CFG 10
 template <> struct Cfg<12> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
+// CFG 13 / 14: CFG 12's tile with the K loop dealt over KG groups of four waves INSIDE the workgroup (group g multiplies
+// K-tiles g, g + KG, ...; each group has its own LDS-DMA ring; the partial accumulators meet in LDS before the epilogue).
+// On grids of at most one workgroup per CU the K loop of CFG 12 is a dependent chain per K-tile and wave (barrier ->
+// DMA issue -> fragment reads -> four dependent MFMAs: ~0.4 us per 64-deep K-tile whatever feeds LDS - a deeper DMA
+// ring (8 stages) and a ring of registers filled by plain global loads with counted waits both measured level with
+// the 4-stage DMA ring); a second / third wave per SIMD on OTHER K-tiles overlaps those chains.
+// CFG 13: KG = 2, 4-stage rings (128 KiB); CFG 14: KG = 3, 3-stage rings (144 KiB).  K % 64 == 0 only (no tail zeroing).
+template <> struct Cfg<13> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
+template <> struct Cfg<14> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 3; static constexpr bool SPEC = false; };
+template <int CFG> constexpr int kKG = CFG == 13 ? 2 : (CFG == 14 ? 3 : 1);
 // (the same split of the 128x128 tile over sixteen 32x32 waves was measured and dropped: 73 VGPRs allow one
 // workgroup per CU instead of two, 135 vs 92 us on M 12000, N 3072, K 768)
 template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // ABL (diagnostics, compile-time so the production loop is untouched): 2 = no MFMA/fragment reads,
 // 4 = no staging after the prologue
 template <typename TC, bool A_KS, bool B_KS, int CFG, int ABL = 0>
-__global__ __launch_bounds__((Cfg<CFG>::BM / Cfg<CFG>::WM) * (Cfg<CFG>::BN / Cfg<CFG>::WN) * (Cfg<CFG>::SPEC ? 128 : 64))
+__global__ __launch_bounds__((Cfg<CFG>::BM / Cfg<CFG>::WM) * (Cfg<CFG>::BN / Cfg<CFG>::WN) * (Cfg<CFG>::SPEC ? 128 : 64) * kKG<CFG>)
 void gemm_fast_kernel(const FastParams P) {
   using K = Cfg<CFG>;
   constexpr int BM = K::BM, BN = K::BN, NSTAGE = K::NSTAGE;
@@ -517,10 +527,13 @@ void gemm_fast_kernel(const FastParams P) {
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   const int64_t bz = blockIdx.z;
   const int lane = threadIdx.x & 63;
+  constexpr int KG = kKG<CFG>;                // K-groups of NW waves (CFG 13 / 14)
+  static_assert(KG == 1 || !K::SPEC, "K-groups and loader waves do not combine");
   const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool loader = K::SPEC && wave_all >= NW;       // wave-uniform role
-  const bool consumer = !K::SPEC || wave_all < NW;
-  const int wave = loader ? wave_all - NW : wave_all;  // index within its role
+  const bool consumer = !K::SPEC || wave_all < NW || KG > 1;
+  const int kgroup = KG > 1 ? wave_all / NW : 0;
+  const int wave = KG > 1 ? wave_all - kgroup * NW : (loader ? wave_all - NW : wave_all);  // index within its role / group
   const int wr = wave / WCOLS, wc = wave % WCOLS;
   constexpr int NTHREADS = NW * (K::SPEC ? 128 : 64);
 
@@ -646,25 +659,55 @@ void gemm_fast_kernel(const FastParams P) {
     // issued (past the last tile the last one is re-fetched into a slot nobody reads) to keep that
     // count exact.  One barrier per K-tile: it publishes tile t and retires the reads of tile t-1,
     // whose slot the stage issued right after it overwrites.
+    // K-groups (KG > 1): group g walks tiles g, g + KG, ... in its own ring; every group makes the same number of trips
+    // (and barrier calls), a group whose tile is past the end re-fetches the last tile and skips the MFMAs.
     if (nt > 0) {
       constexpr int LPT = PA + PB;
       static_assert((NSTAGE - 2) * LPT <= 63, "vmcnt is a 6-bit counter");
       const int last = it0 + nt - 1;
+      char* ring = smem + kgroup * (NSTAGE * STAGE);
+      auto gstage = [&](int it, int buf) {
+        char* As = ring + buf * STAGE;
+        char* Bs = As + A_BYTES;
+        walk(it, [&](const bf16_t* src, int, int j) { glds16(src, As + j * 1024); },
+             [&](const bf16_t* src, int, int j) { glds16(src, Bs + j * 1024); });
+      };
 #pragma unroll
-      for (int s_ = 0; s_ < NSTAGE - 1; ++s_) stage(min(it0 + s_, last), s_);
+      for (int s_ = 0; s_ < NSTAGE - 1; ++s_) gstage(min(it0 + kgroup + KG * s_, last), s_);
       int slot = 0, fill = NSTAGE - 1;
-      for (int t = 0; t < nt; ++t) {
+      const int trips = (nt + KG - 1) / KG;
+      for (int t = 0; t < trips; ++t) {
         wait_vmcnt<(NSTAGE - 2) * LPT>();
         __syncthreads();
-        stage(min(it0 + t + NSTAGE - 1, last), fill);
-        zero_tail(it0 + t, slot);
-        const char* As = smem + slot * STAGE;
-        mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
+        gstage(min(it0 + kgroup + KG * (t + NSTAGE - 1), last), fill);
+        if constexpr (KG == 1) zero_tail(it0 + t, slot);
+        const char* As = ring + slot * STAGE;
+        if (KG == 1 || kgroup + KG * t < nt)
+          mma_tile<A_KS, B_KS, MI, NI, BM == 64, BN == 64>(As, As + A_BYTES, wr * K::WM, wc * K::WN, lane, acc);
         slot = slot + 1 == NSTAGE ? 0 : slot + 1;
         fill = fill + 1 == NSTAGE ? 0 : fill + 1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetched tail tiles must land before LDS is reused
       __syncthreads();
+    }
+    if constexpr (KG > 1) {
+      // partial accumulators of groups 1 .. KG-1 meet group 0's in LDS: [group - 1][wave][register][lane] fp32, behind
+      // the epilogue staging of group 0 (NW x 4 KiB)
+      static_assert(MI == 1 && NI == 1, "K-groups are written for one 32x32 accumulator per wave");
+      float* part = reinterpret_cast<float*>(smem + NW * 4096);
+      if (kgroup > 0) {
+        float* dst = part + ((kgroup - 1) * NW + wave) * 1024;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[e * 64 + lane] = acc[0][0][e];
+      }
+      __syncthreads();
+      if (kgroup > 0) return;
+#pragma unroll
+      for (int g = 1; g < KG; ++g) {
+        const float* src = part + ((g - 1) * NW + wave) * 1024;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += src[e * 64 + lane];
+      }
     }
   } else
   if (nt > 0) {
@@ -1012,7 +1055,7 @@ template <typename TC, bool A_KS, bool B_KS, int CFG>
 int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   using K = Cfg<CFG>;
   constexpr int NW = (K::BM / K::WM) * (K::BN / K::WN);
-  constexpr int LDS_BYTES = K::NSTAGE * (K::BM + K::BN) * 128;
+  constexpr int LDS_BYTES = kKG<CFG> * K::NSTAGE * (K::BM + K::BN) * 128;
   static_assert(LDS_BYTES >= NW * (K::WN == 32 ? 4096 : 8192), "epilogue staging must fit the ring");
   FastParams P;
   P.d = d;
@@ -1114,9 +1157,9 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
   if (ws_split) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
-    hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, Q);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64) * kKG<CFG>), LDS_BYTES, stream, Q);
   });
-  hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64)), LDS_BYTES, stream, P);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64) * kKG<CFG>), LDS_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm(fast)");
 }
 
@@ -1235,12 +1278,18 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 11) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
   if (force == 12 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
   if (force == 13 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
+  if (force == 15 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
+  if (force == 16 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 14>(d, stream);
   if (small) {
     // measured (tools/gemm_small.py, M = 800): four waves of 32x32 beat two of 32x64 wherever the grid is
     // at most one workgroup per CU (N 768, K 768: 12.3 -> 9.1 us) and tie elsewhere; the 4-stage ring adds
     // to that for long K on such grids (N 768, K 3072: 27.4 -> 21.4 us) and loses co-residency on larger ones
     const int64_t tiles64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.nbatch;
     if (d.splitk <= 1) {
+      // at most one workgroup per CU: two K-groups of four waves overlap each other's per-K-tile chains
+      // (tools/gemm_small2.py, M 800 N 768: K 3072 22.9 -> 17.4 us, K 768 9.2 -> 8.7 us; a third group adds nothing)
+      static const int no_kg = [] { const char* e = getenv("TMI_GEMM_NO_KGROUPS"); return e ? atoi(e) : 0; }();
+      if (!no_kg && tiles64 <= 256 && d.kbatch == 1 && d.K % 64 == 0 && d.K >= 512) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
       if (tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
       return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
     }

@@ -30,9 +30,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         out.append((f"wgrd KS,KS out {Mo}x{No} K{M}", bench(lambda: ops.gemm(X, DY, G, Mo, No, M, 1, Mo, No, 1, No, splitk=0))))
     for k, v in out:
         print(f"{k:36s} {v:7.1f}")
+    # correctness of whatever configuration is forced, on ragged sizes too (stderr: the parent only parses timings)
+    for (M2, N2, K2) in ((800, 768, 768), (800, 768, 3072), (333, 200, 448), (64, 64, 64), (130, 72, 1024)):
+        X = torch.randn(M2, K2, device=dev).to(bf); Wt = torch.randn(N2, K2, device=dev).to(bf); W = torch.randn(K2, N2, device=dev).to(bf)
+        Y = torch.empty(M2, N2, device=dev, dtype=bf)
+        ops.gemm(X, W, Y, M2, N2, K2, K2, 1, N2, 1, N2)
+        e1 = (Y.float() - X.float() @ W.float()).abs().max().item() / (X.float() @ W.float()).abs().max().item()
+        ops.gemm(X, Wt, Y, M2, N2, K2, K2, 1, 1, K2, N2)
+        e2 = (Y.float() - X.float() @ Wt.float().t()).abs().max().item() / (X.float() @ Wt.float().t()).abs().max().item()
+        print(f"check cfg={os.environ.get('TMI_GEMM_CFG', 'auto')} M{M2} N{N2} K{K2}: rel err fwd {e1:.2e} dgrad {e2:.2e}", file=sys.stderr)
+        assert e1 < 1e-2 and e2 < 1e-2
     sys.exit(0)
 res = {}
-cfgs = ["", "12", "13", "11", "6", "4"]
+cfgs = ["", "12", "13", "15", "16", "11", "6"]
 for c in cfgs:
     env = dict(os.environ)
     if c:
@@ -45,6 +55,8 @@ for c in cfgs:
             res.setdefault(line[:36], {})[c or "auto"] = float(line[36:])
     if p.returncode:
         print("cfg", c, "failed:", p.stderr[-300:])
-print(f"{'shape':36s} " + " ".join(f"{(c or 'auto'):>7s}" for c in cfgs) + "   (us; cfg 12 = 64x64 4 waves, 13 = + 4-stage ring, 11 = 2 waves ring, 6 = 2 waves, 4 = 128x128)")
+    elif c in ("15", "16"):
+        print(p.stderr.strip())
+print(f"{'shape':36s} " + " ".join(f"{(c or 'auto'):>7s}" for c in cfgs) + "   (us; cfg 12 = 64x64 4 waves, 13 = + 4-stage ring, 15 = K-groups 2x4 waves, 16 = K-groups 3x4 waves, 11 = 2 waves ring, 6 = 2 waves)")
 for k, v in res.items():
     print(f"{k:36s} " + " ".join(f"{v.get(c or 'auto', float('nan')):7.1f}" for c in cfgs))
