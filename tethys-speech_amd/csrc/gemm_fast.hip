@@ -49,6 +49,7 @@ struct FastParams {
   int tiles_m, tiles_n, ktiles;
   int xm, xn;        // XCD partition of the tile grid: xm * xn == 8
   int ptm, ptn;      // tiles per XCD partition along m / n
+  int walk_m;        // consecutive workgroups of an XCD walk along m (sharing a B panel) instead of along n (sharing an A panel)
   int wide;          // epilogue may use 16-byte accesses on C / aux / resid
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
@@ -449,16 +450,17 @@ template <> struct Cfg<10> { static constexpr int BM = 64, BN = 64, WM = 32, WN 
 template <> struct Cfg<11> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 2; static constexpr bool SPEC = false; };
 // CFG 12: CFG 11 with the 4-stage ring of CFG 10
 template <> struct Cfg<12> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
-// CFG 13 / 14: CFG 12's tile with the K loop dealt over KG groups of four waves INSIDE the workgroup (group g multiplies
-// K-tiles g, g + KG, ...; each group has its own LDS-DMA ring; the partial accumulators meet in LDS before the epilogue).
-// On grids of at most one workgroup per CU the K loop of CFG 12 is a dependent chain per K-tile and wave (barrier ->
-// DMA issue -> fragment reads -> four dependent MFMAs: ~0.4 us per 64-deep K-tile whatever feeds LDS - a deeper DMA
-// ring (8 stages) and a ring of registers filled by plain global loads with counted waits both measured level with
-// the 4-stage DMA ring); a second / third wave per SIMD on OTHER K-tiles overlaps those chains.
-// CFG 13: KG = 2, 4-stage rings (128 KiB); CFG 14: KG = 3, 3-stage rings (144 KiB).  K % 64 == 0 only (no tail zeroing).
+// CFG 13: CFG 12's tile with the K loop dealt over KG = 2 groups of four waves INSIDE the workgroup (group g multiplies
+// K-tiles g, g + KG, ...; each group has its own 4-stage LDS-DMA ring, 128 KiB in all; the partial accumulators meet in
+// LDS before the epilogue).  On grids of at most one workgroup per CU the K loop of CFG 12 is a dependent chain per K-tile
+// and wave (barrier -> DMA issue -> fragment reads -> four dependent MFMAs: ~0.4 us per 64-deep K-tile whatever feeds LDS:
+// an 8-stage DMA ring and a ring of registers filled by plain global loads with counted waits both measured level with the
+// 4-stage DMA ring); a second wave per SIMD on OTHER K-tiles overlaps those chains (0.24 us per K-tile; a third group adds
+// nothing: that is the CU's fill rate), and with the weights arriving from HBM, as they do in the step, the two rings'
+// six K-tiles in flight matter more still (M 800, N 768, K 768, cold weights: 13.5 us on CFG 11, 9.4 on CFG 12, 8.9 here).
+// K % 64 == 0 only (no tail zeroing).
 template <> struct Cfg<13> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
-template <> struct Cfg<14> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 3; static constexpr bool SPEC = false; };
-template <int CFG> constexpr int kKG = CFG == 13 ? 2 : (CFG == 14 ? 3 : 1);
+template <int CFG> constexpr int kKG = CFG == 13 ? 2 : 1;
 // (the same split of the 128x128 tile over sixteen 32x32 waves was measured and dropped: 73 VGPRs allow one
 // workgroup per CU instead of two, 135 vs 92 us on M 12000, N 3072, K 768)
 template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
@@ -521,7 +523,9 @@ void gemm_fast_kernel(const FastParams P) {
   // blockIdx.x % 8 labels the XCD.  The tile grid is cut into xm x xn rectangles, one per XCD,
   // sized so that an XCD's slice of B stays resident in its 4 MiB L2 while A panels stream.
   const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-  const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
+  int ltm, ltn;
+  if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
+  else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
   const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
   if (tm >= P.tiles_m || tn >= P.tiles_n) return;  // padding block of a ragged partition (whole workgroup)
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
@@ -809,7 +813,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB]
   const tmi_gemm_desc& d = P.d;
   const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-  const int ltm = lidx / P.ptn, ltn = lidx - ltm * P.ptn;
+  int ltm, ltn;
+  if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
+  else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
   const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
   if (tm >= P.tiles_m || tn >= P.tiles_n) return;
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * 256;
@@ -1051,6 +1057,19 @@ int launch_with_slabs(const FastParams& P, int splitk, hipStream_t stream, F&& l
   return tmi_check_launch("tmi_gemm(split-K reduce)");
 }
 
+// Order of an XCD's workgroups inside its rectangle of the tile grid.  Workgroups that are resident together should
+// share the panel of the operand that does NOT fit the XCD's L2 (it is then fetched once while they run), and re-read
+// the other operand from L2.  Walking along n (consecutive workgroups share an A row-panel) suits activations x
+// weights (M = 12000: A is the stream, the weights stay in L2); the LM head (M = 800, N = 51904: 80 MB of weights,
+// 1.2 MB of activations) and its weight gradient want the opposite, or every row-tile re-fetches each weight panel.
+inline int walk_along_m(const tmi_gemm_desc& d, int xm, int xn) {
+  static const int force = [] { const char* e = getenv("TMI_GEMM_WALK_M"); return e ? atoi(e) : -1; }();
+  if (force >= 0) return force;
+  const double a_share = (double)d.M * (double)d.K * (double)d.kbatch * 2.0 / xm;  // bytes of A one XCD touches
+  const double b_share = (double)d.N * (double)d.K * (double)d.kbatch * 2.0 / xn;
+  return b_share > 3.0 * 1048576.0 && a_share < b_share;
+}
+
 template <typename TC, bool A_KS, bool B_KS, int CFG>
 int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   using K = Cfg<CFG>;
@@ -1079,7 +1098,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
     if ((dbg & 6) == 4) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 4>;
     if (dbg == 8) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 8>;
-    if (dbg & 14) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (dbg & 14) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<TC, A_KS, B_KS, CFG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1114,6 +1133,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   P.xm = 8 / xn;
   P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
   P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  P.walk_m = walk_along_m(d, P.xm, P.xn);
   int splitk = d.splitk > 1 ? d.splitk : 1;
   if (d.splitk == 0 && d.out_dtype == TMI_F32 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in &&
       !d.resid && d.scale_cols <= 0) {
@@ -1220,6 +1240,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   P.xm = 8 / xn;
   P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
   P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  P.walk_m = walk_along_m(d, P.xm, P.xn);
   // split-K (library-chosen only, fp32 output, workspace slabs only): fill the 256 CUs, >= 6 K-tiles per split
   int splitk = 1;
   if constexpr (sizeof(TC) == 4) {
@@ -1279,7 +1300,6 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 12 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
   if (force == 13 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
   if (force == 15 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
-  if (force == 16 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 14>(d, stream);
   if (small) {
     // measured (tools/gemm_small.py, M = 800): four waves of 32x32 beat two of 32x64 wherever the grid is
     // at most one workgroup per CU (N 768, K 768: 12.3 -> 9.1 us) and tie elsewhere; the 4-stage ring adds
@@ -1289,7 +1309,7 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
       // at most one workgroup per CU: two K-groups of four waves overlap each other's per-K-tile chains
       // (tools/gemm_small2.py, M 800 N 768: K 3072 22.9 -> 17.4 us, K 768 9.2 -> 8.7 us; a third group adds nothing)
       static const int no_kg = [] { const char* e = getenv("TMI_GEMM_NO_KGROUPS"); return e ? atoi(e) : 0; }();
-      if (!no_kg && tiles64 <= 256 && d.kbatch == 1 && d.K % 64 == 0 && d.K >= 512) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
+      if (!no_kg && tiles64 <= 256 && d.K % 64 == 0 && d.K * d.kbatch >= 512) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
       if (tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
       return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
     }
