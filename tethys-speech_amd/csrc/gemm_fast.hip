@@ -461,8 +461,6 @@ template <> struct Cfg<12> { static constexpr int BM = 64, BN = 64, WM = 32, WN 
 // K % 64 == 0 only (no tail zeroing).
 template <> struct Cfg<13> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
 template <int CFG> constexpr int kKG = CFG == 13 ? 2 : 1;
-// (the same split of the 128x128 tile over sixteen 32x32 waves was measured and dropped: 73 VGPRs allow one
-// workgroup per CU instead of two, 135 vs 92 us on M 12000, N 3072, K 768)
 template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
 
 // Split-K through the workspace: every split runs the ordinary (non-atomic) epilogue into its own
