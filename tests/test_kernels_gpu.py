@@ -133,6 +133,34 @@ def test_gemm_kbatch_splitk(dev):
         assert rel_err(dW, ref) <= 2e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(800, 768, 768), (333, 200, 448), (64, 64, 64), (130, 72, 1024), (800, 768, 576)])
+def test_gemm_k_groups_inside_the_workgroup(dev, M, N, K):
+    """Grids of at most one 64x64 tile per CU with K % 64 == 0 run two K-groups of four waves (gemm_fast.hip CFG 13): group g
+    multiplies K-tiles g, g + 2, ... and the partial accumulators meet in LDS.  Odd and even trip counts (K = 576: 9 tiles,
+    K = 64: one tile, the second group idle), ragged edges, the whole epilogue (bias, saved pre-activation, GELU, residual),
+    and the qkv-dgrad form whose reduction runs over three K batches."""
+    ops = _ops()
+    bf = torch.bfloat16
+    A = rnd((M, K), bf, dev, 41)
+    W = rnd((K, N), bf, dev, 42, 0.1)
+    bias = rnd((N,), torch.float32, dev, 43)
+    R = rnd((M, N), bf, dev, 44)
+    pre = A.double() @ W.double() + bias.double()
+    ref = torch.nn.functional.gelu(pre) + R.double()
+    for Bm, bsk, bsn in ((W, N, 1), (W.t().contiguous(), 1, K)):
+        Cm = torch.full((M, N), float("nan"), dtype=bf, device=dev)
+        U = torch.full((M, N), float("nan"), dtype=bf, device=dev)
+        ops.gemm(A, Bm, Cm, M, N, K, K, 1, bsk, bsn, N, bias=bias, act=1, aux_out=U, resid=R, r_ld=N)
+        assert rel_err(U, pre) <= 1.5e-2 and rel_err(Cm, ref) <= 1.5e-2
+    if K % 192 == 0:  # dX = sum_j dY[:, j-th block] @ W_j^T, W_j = three [H, H] kernels side by side (W:89-92's q / k / v)
+        H = K // 3
+        Wq = rnd((3, H, N), bf, dev, 45, 0.1)           # [j][k][n]
+        Cm = torch.empty((M, N), dtype=bf, device=dev)
+        ops.gemm(A, Wq, Cm, M, N, H, K, 1, N, 1, N, kbatch=3, a_skb=H, b_skb=H * N)
+        ref3 = sum(A[:, j * H:(j + 1) * H].double() @ Wq[j].double() for j in range(3))
+        assert rel_err(Cm, ref3) <= 1.5e-2
+
+
 # ----------------------------------------------------------------------------- LayerNorm etc.
 # Shapes below are chosen to land on the shape-selected fast paths of gemm_fast.hip: the eight-phase
 # 256x256 kernel (k-contiguous A with either B layout; M >= 2048, long K or a light epilogue), its
