@@ -335,22 +335,27 @@ class KernelBlocks:
             raise RuntimeError(f"{name_fmt}: layers are not at a constant arena stride")
         return stride
 
-    def _wgrad_batched(self, x_stack, dy_stack, wname_fmt, L, bias=True):
+    def _wgrad_batched(self, x_stack, dy_stack, wname_fmt, L, bias=True, lo=0, hi=None):
         """dW_l = x_lᵀ · dy_l (and db_l = colsum(dy_l)) for every layer l in ONE launch each: the deferred form of
         ``_dense_bwd``'s weight gradient.  At M = B * 100 rows a layer's weight gradient is a 13-26 us launch that cannot
         fill the chip (Wav2Vec2: 58 of them per step, the Whisper decoder 24); L of them side by side are one GEMM with L
         times the tiles.  x_stack [L, M, K_in], dy_stack [L, M, N] (``_buf_layers``); the gradient arena supplies the
-        constant stride on the output side."""
+        constant stride on the output side.  ``lo`` / ``hi``: only layers [lo, hi) - a chunk whose dy are already final can
+        start while the backward chain is still working on the layers below it."""
         a = self.arena
-        w0 = wname_fmt.format(0)
+        hi = L if hi is None else hi
+        if hi <= lo:
+            return
+        w0 = wname_fmt.format(lo)
         K_in, N = a.shapes[w0][-2], a.shapes[w0][-1]
         M = x_stack.shape[1]
         stride = self._layer_stride(wname_fmt, L)
-        ops.gemm(x_stack, dy_stack, a.grad(w0).view(K_in, N), K_in, N, M, 1, x_stack.stride(1), dy_stack.stride(1), 1, N,
-                 nbatch=L, a_sb=x_stack.stride(0), b_sb=dy_stack.stride(0), c_sb=stride, splitk=0)
+        xs, dys = x_stack[lo:hi], dy_stack[lo:hi]
+        ops.gemm(xs, dys, a.grad(w0).view(K_in, N), K_in, N, M, 1, x_stack.stride(1), dy_stack.stride(1), 1, N,
+                 nbatch=hi - lo, a_sb=x_stack.stride(0), b_sb=dy_stack.stride(0), c_sb=stride, splitk=0)
         b0 = w0.replace(".kernel", ".bias")
         if bias and b0 in a.offsets:
-            ops.bias_grad_batched(dy_stack, a.grad(b0), self._layer_stride(wname_fmt.replace(".kernel", ".bias"), L))
+            ops.bias_grad_batched(dys, a.grad(b0), self._layer_stride(wname_fmt.replace(".kernel", ".bias"), L))
 
     def check_workspace_guards(self):
         """Names of workspace buffers whose guard zone (TMI_WS_GUARD=<elements>) was written: a kernel ran past their end."""

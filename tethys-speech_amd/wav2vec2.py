@@ -498,6 +498,33 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                     dy.copy_(dres)
             return dy
 
+        # The batched weight gradients go to the second stream in CHUNKS of layers (TMI_WGRAD_CHUNKS, default 4): a chunk
+        # starts as soon as the backward chain has left its layers - that chain is a string of decoder-sized kernels on a
+        # mostly idle chip - instead of everything queueing behind layer 0 and running into the conv-stack backward, whose
+        # own weight gradients share that stream (measured with those on it, ms/step: 1 chunk 4.74, 2: 4.75, 3: 4.71, 4: 4.70).
+        nchunk = max(1, min(Lh, int(os.environ.get("TMI_WGRAD_CHUNKS", "4")))) if batch else 1
+        cuts = sorted({(Lh * j) // nchunk for j in range(nchunk)})   # chunk j = layers [cuts[j], cuts[j + 1])
+        st = {n: ws[f"enc*.{n}"] for n in ("xn1", "ctx", "xn2", "g", "dqkv", "dya", "dU", "dyf")} if batch else None
+        lay = "encoder.layers.{}"
+
+        def encoder_weight_grads(lo, hi):
+            # the bias gradients the LayerNorm backward did not emit: every layer's with TMI_LN_EMIT=0, the top layer's
+            # output_dense otherwise (its dres came from the projection head)
+            self._wgrad_batched(st["g"], st["dyf"], lay + ".feed_forward.output_dense.kernel", Lh, bias=not emit_on, lo=lo, hi=hi)
+            if emit_on and hi == Lh:
+                ops.bias_grad(st["dyf"][Lh - 1], a.grad(lay.format(Lh - 1) + ".feed_forward.output_dense.bias"))
+            self._wgrad_batched(st["xn2"], st["dU"], lay + ".feed_forward.intermediate_dense.kernel", Lh, lo=lo, hi=hi)
+            self._wgrad_batched(st["ctx"], st["dya"], lay + ".attention.out_proj.kernel", Lh, bias=not emit_on, lo=lo, hi=hi)
+            # the q / k / v blocks are three [H, H] kernels side by side in the arena: one launch per block over the layers
+            gq0 = a.grad(lay.format(lo) + ".attention.qkv3.kernel")
+            lstride = self._layer_stride(lay + ".attention.qkv3.kernel", Lh)
+            xn1, dqs = st["xn1"][lo:hi], st["dqkv"][lo:hi]
+            for j in range(3):
+                ops.gemm(xn1, dqs, gq0, H, H, R, 1, H, 3 * H, 1, H, nbatch=hi - lo, a_sb=R * H, b_sb=R * 3 * H,
+                         c_sb=lstride, b_off=j * H, c_off=j * H * H, splitk=0)
+            ops.bias_grad_batched(dqs, a.grad(lay.format(lo) + ".attention.qkv3.bias"),
+                                  self._layer_stride(lay + ".attention.qkv3.bias", Lh))
+
         for i in reversed(range(Lh)):
             p, kk = f"encoder.layers.{i}", f"enc{i}."
             dU, dt_, dctx, dqkv = ws[kk + "dU"], ws["dtmp"], ws["dctx"], ws[kk + "dqkv"]
@@ -532,29 +559,11 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             self._ln_bwd(dt_, ws[kk + "x_in"], p + ".attention_layer_norm", dres, kk + "ln1", True,
                          emit=emit(f"encoder.layers.{i - 1}.feed_forward.output_dense.bias", f"enc{i - 1}.dyf",
                                    SITE_FFN_OUT + i - 1) if i > 0 else None)
-
-        if batch:
-            st = {n: ws[f"enc*.{n}"] for n in ("xn1", "ctx", "xn2", "g", "dqkv", "dya", "dU", "dyf")}
-            lay = "encoder.layers.{}"
-
-            def encoder_weight_grads():
-                # the bias gradients the LayerNorm backward did not emit: every layer's with TMI_LN_EMIT=0, the top layer's
-                # output_dense otherwise (its dres came from the projection head)
-                self._wgrad_batched(st["g"], st["dyf"], lay + ".feed_forward.output_dense.kernel", Lh, bias=not emit_on)
-                if emit_on:
-                    ops.bias_grad(st["dyf"][Lh - 1], a.grad(lay.format(Lh - 1) + ".feed_forward.output_dense.bias"))
-                self._wgrad_batched(st["xn2"], st["dU"], lay + ".feed_forward.intermediate_dense.kernel", Lh)
-                self._wgrad_batched(st["ctx"], st["dya"], lay + ".attention.out_proj.kernel", Lh, bias=not emit_on)
-                # the q / k / v blocks are three [H, H] kernels side by side in the arena: one launch per block over all layers
-                gq0 = a.grad(lay.format(0) + ".attention.qkv3.kernel")
-                lstride = self._layer_stride(lay + ".attention.qkv3.kernel", Lh)
-                for j in range(3):
-                    ops.gemm(st["xn1"], st["dqkv"], gq0, H, H, R, 1, H, 3 * H, 1, H, nbatch=Lh, a_sb=R * H, b_sb=R * 3 * H,
-                             c_sb=lstride, b_off=j * H, c_off=j * H * H, splitk=0)
-                ops.bias_grad_batched(st["dqkv"], a.grad(lay.format(0) + ".attention.qkv3.bias"),
-                                      self._layer_stride(lay + ".attention.qkv3.bias", Lh))
-            # under the feature-projection / positional-conv / conv-stack backward that follows on the main stream
-            self._run_on_side(encoder_weight_grads, st["dqkv"])
+            if batch and i in cuts:
+                # every dy of layers [i, next cut) is final (this layer's dqkv was the last to be written); the rest of the
+                # step runs beside this chunk: the layers below, then the feature-projection / pos-conv / conv-stack backward
+                lo, hi = i, ([c for c in cuts if c > i] + [Lh])[0]
+                self._run_on_side(lambda lo=lo, hi=hi: encoder_weight_grads(lo, hi), ws[kk + "dqkv"])
 
         # hproj feeds the encoder only (the quantiser branch is non-differentiable)
         if drop:
@@ -569,8 +578,18 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         ops.bias_grad(dhp, a.grad("feature_extractor.pos_conv_embed.bias"))
         ops.group_pack(dhp, ws["dyg"], B, T, C, Gn, self.Tpp, 0)
         gwp = a.grad("feature_extractor.pos_conv_embed.kernel")
-        ops.gemm(ws["xg"], ws["dyg"], gwp, k * Cg, Cg, Mw, 1, Cg, Cg, 1, C, nbatch=Gn, a_sb=B * self.Tpp * Cg,
-                 b_sb=B * self.Tpp * Cg, c_sb=Cg, splitk=0)
+        # (weight gradients of the positional conv and of the conv stack feed nothing on the chain: second stream.  Their
+        # operands - the packed / padded forward inputs and the per-layer dy buffers - are not rewritten before the join)
+        conv_side = os.environ.get("TMI_CONV_WGRAD_SIDE", "1") != "0"
+
+        def off_chain(fn, dy):
+            if conv_side:
+                self._run_on_side(fn, dy)
+            else:
+                fn()
+
+        off_chain(lambda: ops.gemm(ws["xg"], ws["dyg"], gwp, k * Cg, Cg, Mw, 1, Cg, Cg, 1, C, nbatch=Gn, a_sb=B * self.Tpp * Cg,
+                                   b_sb=B * self.Tpp * Cg, c_sb=Cg, splitk=0), ws["dyg"])
         ops.group_pack(dhp, ws["dyg2"], B, T, C, Gn, self.Tpp2, k - 1)
         Mw2 = B * self.Tpp2 - (k - 1)
         ops.gemm(ws["dyg2"], self.pos_wb, ws["dxg2"], Mw2, Cg, k * Cg, Cg, 1, Cg, 1, Cg, nbatch=Gn,
@@ -602,8 +621,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             wname = f"feature_extractor.conv_layers.{i}.conv.kernel"
             xin = ws[f"in{i}"]
             gw = a.grad(wname).view(kc * cin, c)
-            ops.gemm(xin, dup, gw, kc * cin, c, Ti, 1, s * cin, c, 1, c, kbatch=B, a_skb=xin.stride(0),
-                     b_skb=dup.stride(0), b_off=c, splitk=0)
+            off_chain(lambda xin=xin, dup=dup, gw=gw, kc=kc, cin=cin, c=c, Ti=Ti, s=s:
+                      ops.gemm(xin, dup, gw, kc * cin, c, Ti, 1, s * cin, c, 1, c, kbatch=B, a_skb=xin.stride(0),
+                               b_skb=dup.stride(0), b_off=c, splitk=0), dup)
             if i == 0:
                 continue
             if s != 2 or kc not in (2, 3):

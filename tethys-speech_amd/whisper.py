@@ -740,10 +740,18 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # one launch over the B per-sample spans (du2 skips the zero row 0 of every sample)
         ops.gelu_bwd_batched(dres, ws["u2"], du2, T * d, B, T * d, T * d, du2pad.stride(0))
         # the pad rows of du2pad are zero, so the bias gradient is one column sum over the whole buffer
-        ops.bias_grad(du2pad.view(-1, d), a.grad("encoder.conv2.bias"))
         gw2 = a.grad("encoder.conv2.kernel").view(3 * d, d)
-        ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
-                 b_skb=du2pad.stride(0), b_off=d, splitk=0)
+
+        def conv2_weight_grads():
+            ops.bias_grad(du2pad.view(-1, d), a.grad("encoder.conv2.bias"))
+            ops.gemm(h1pad, du2pad, gw2, 3 * d, d, T, 1, 2 * d, d, 1, d, kbatch=B, a_skb=h1pad.stride(0),
+                     b_skb=du2pad.stride(0), b_off=d, splitk=0)
+        # conv2's weight gradient (88 us + its split-K reduce) feeds nothing on the chain: beside the two dgrad launches
+        # below (du2pad and h1pad are not rewritten before the join)
+        if os.environ.get("TMI_CONV_WGRAD_SIDE", "1") != "0":
+            self._run_on_side(conv2_weight_grads, du2pad)
+        else:
+            conv2_weight_grads()
         sd = du2pad.stride(0)
         # even padded rows u = 2j: dY[j]·W0ᵀ + dY[j-1]·W2ᵀ  (kbatch walks the two kernel taps)
         ops.gemm(du2pad, w2, dh1pad, T, d, d, d, 1, 1, ld2, 2 * d, nbatch=B, a_sb=sd, c_sb=dh1pad.stride(0),
