@@ -455,7 +455,9 @@ def main():
             batch = next(it)
             if batch[0].shape[0] != args.batch_size:
                 raise RuntimeError(f"rank {rank} drew {batch[0].shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
-            return train.distributed_train_step(strategy, model, batch, opt)
+            # pipelined: the next call is another step (the decoder layers' Adam slice runs under its encoder forward); the
+            # timed region ends with a device-wide synchronize, which covers the last one
+            return train.distributed_train_step(strategy, model, batch, opt, pipelined=True)
         c = model.config
         metric = f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)"
         workload = (f"whisper-{args.model_type}-ref (reference '{args.model_type}': {c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, "
@@ -487,7 +489,8 @@ def main():
             audio = next(it)
             if audio.shape[0] != args.batch_size:
                 raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
-            return train.wav2vec2_train_step(strategy, model, audio, negs[ctr[0] % len(negs)], opt)
+            # (pipelined: see the Whisper step above)
+            return train.wav2vec2_train_step(strategy, model, audio, negs[ctr[0] % len(negs)], opt, pipelined=True)
         metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
         workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
         gf_sample = W2V_GF_PER_SAMPLE.get(size)

@@ -269,7 +269,9 @@ int tmi_adam_step_segments(float* p, float* g, float* m, float* v, const int64_t
                            int64_t nchunks, const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr,
                            float beta1, float beta2, float eps, int32_t step, int32_t eps_mode,
                            float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
-                           void* stream);
+                           int32_t max_blocks, void* stream);
+/* (max_blocks > 0 caps the grid, as in tmi_adam_step: for a slice of the table that runs beside other work.  The global
+ * norm always comes from the whole sumsq[nseg], so a sub-table of chunks is the same update restricted to its rows.) */
 /* The step-dependent scalars of tmi_adam_step, computed on the host exactly as it does:
  * out3 = {step_size, vcorr_inv_sqrt, 1 - lr*weight_decay}. */
 int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step, int32_t eps_mode,

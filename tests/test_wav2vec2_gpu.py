@@ -559,3 +559,47 @@ def test_fir_conv0_groupnorm_gelu_fused(dev, dtype, B, Tin, C, G):
     ops.fir_groupnorm_gelu_bwd(audio, pl, w, k, s, dy, dy.stride(0), gamma, beta, stats, dW, dg, db, part, sums, wpart, B, T, C, G,
                                dy_off=C)
     assert rel_err(dW, 2 * wr.grad) <= tol
+
+
+def test_pipelined_wav2vec2_steps_leave_the_same_model(dev):
+    """``wav2vec2_train_step(..., pipelined=True)`` leaves the clipped Adam update of encoder layer L/3 and everything after it
+    running on the second stream (train.ADAM_LATE); the next step's forward waits for it at that layer.  Same arithmetic
+    (the global norm comes from the complete sum-of-squares table), so the model after N such steps is the model after N
+    plain steps, up to the fp32-atomic noise two plain runs show between themselves; the quantiser's code choices (hard
+    argmin: one flip changes the loss visibly) must be the same at every step."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist, optim, train, wav2vec2
+    kw = dict(small_cfg(), num_hidden_layers=3)
+    B, T_in = 2, 400
+    pool = V.create_dummy_pool(seed=3, num_samples=8, length=T_in)
+    ocfg = V.make_config("base", **kw)
+    T = V.feature_lengths(ocfg, T_in)[-1]
+
+    def run(pipelined):
+        model = wav2vec2.create_full_model("pretraining", "base", device=dev, precision="fp32", seed=11, **kw)
+        assert model._side is not None and model._late_row is not None
+        opt = optim.Adam(learning_rate=1e-3, epsilon=1e-8)
+        strat = dist.DataParallelStrategy(0, 1)
+        rng = np.random.default_rng(77)
+        it = V.batches(pool, B)
+        losses = []
+        for _ in range(6):
+            a = next(it)
+            neg = V.sample_negative_indices(rng, B, T, ocfg.num_negatives)
+            losses.append(train.wav2vec2_train_step(strat, model, torch.from_numpy(np.ascontiguousarray(a)).to(dev),
+                                                    torch.from_numpy(neg).to(dev), opt, pipelined=pipelined))
+        if pipelined:
+            assert model._late_ev is not None, "the late slice never ran: nothing was tested"
+            model.finish_late()
+        return [float(x.item()) for x in losses], model.arena.p.cpu().numpy(), model.arena.m.cpu().numpy()
+
+    assert train.ADAM_LATE
+    l0, p0, m0 = run(False)
+    l1, p1, m1 = run(False)
+    l2, p2, m2 = run(True)
+    noise_l = max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(l1, l0))
+    got_l = max(abs(x - y) / max(1.0, abs(y)) for x, y in zip(l2, l0))
+    assert got_l <= max(2e-5, 4 * noise_l), (l2, l0, noise_l)
+    dp = np.abs(p2 - p0)
+    assert float((dp > 1e-5).mean()) <= 2e-3 + 2 * float((np.abs(p1 - p0) > 1e-5).mean()), (float(dp.max()), float(np.abs(p1 - p0).max()))
+    print(f"plain twice: loss {noise_l:.1e}, max |dp| {float(np.abs(p1 - p0).max()):.1e}; pipelined vs plain: loss {got_l:.1e}, max |dp| {float(dp.max()):.1e}")

@@ -229,3 +229,46 @@ def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     within(f"whisper small-ref B=8 10-step golden {precision} max |dloss|", max(err), tol, (err, got, gold["losses"]))
     if precision == "fp32":  # the north star's 1e-3 is the contract; what the fp32 path actually holds is ~1e-6
         assert max(err) <= 1e-5, err
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pipelined_steps_leave_the_same_model(dev, precision):
+    """``distributed_train_step(..., pipelined=True)`` returns while the decoder layers' Adam slice is still running on the
+    second stream (train.ADAM_LATE); the next step's decoder waits for it, ``finish_late`` / ``save_checkpoint`` order
+    other readers behind it.  Per-parameter arithmetic is unchanged, so N pipelined steps must leave the model N plain
+    steps leave - up to the run-to-run noise of the step's fp32 atomics, measured by running the plain steps twice.  A
+    missing wait shows as a decoder that trained on stale weights: losses apart by far more than that noise."""
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train, whisper
+    cfg_kw = small_cfg()
+    rng = np.random.default_rng(5)
+    batches = [(rng.standard_normal((3, 16, 48)).astype(np.float32), rng.integers(0, 150, (3, 12)).astype(np.int32))
+               for _ in range(6)]
+
+    def run(pipelined):
+        model = whisper.create_whisper_model("small", device=dev, precision=precision, seed=3, **cfg_kw)
+        assert model._side is not None and model.late_adam_range() is not None
+        opt = optim.Adam(1e-3)
+        strat = D.DataParallelStrategy(0, 1)
+        losses = []
+        for f, l in batches:
+            losses.append(train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)), opt,
+                                                       pipelined=pipelined))
+        if pipelined:
+            assert model._late_ev is not None, "the late slice never ran: nothing was tested"
+            model.finish_late()
+        # (a reader on the default stream after finish_late: exactly what a caller would do)
+        p, m = model.arena.p.cpu().numpy(), model.arena.m.cpu().numpy()
+        return [float(x.item()) for x in losses], p, m
+
+    assert train.ADAM_LATE and train.ADAM_EARLY
+    l0, p0, m0 = run(False)
+    l1, p1, m1 = run(False)
+    l2, p2, m2 = run(True)
+    noise = float(np.abs(p1 - p0).max())
+    assert np.allclose(l2, l0, rtol=2e-6 if precision == "fp32" else 2e-5, atol=1e-6), (l2, l0)
+    dp = np.abs(p2 - p0)
+    # isolated elements whose gradient is pure summation noise may move by an Adam step; regions may not
+    assert float((dp > 1e-5).mean()) <= 2e-3 and float(np.median(dp)) <= 1e-7, (float(dp.max()), noise)
+    assert float(np.abs(m2 - m0).max()) <= 1e-3 * float(np.abs(m0).max())
+    print(f"{precision}: plain twice max |dp| {noise:.1e}; pipelined vs plain {float(dp.max()):.1e}")

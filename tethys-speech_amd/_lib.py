@@ -81,7 +81,7 @@ SIGNATURES = {
     "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),
     "tmi_adam_scalars": (c_i32, [c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp]),
     "tmi_adam_step_segments": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32,
-                                       c_i32, c_f32, c_f32, c_vp, c_i32, c_vp]),
+                                       c_i32, c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),
     "tmi_adam_step_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp, c_i32, c_vp]),
     "tmi_adam_step_dev": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_vp, c_i32, c_f32, c_vp, c_vp]),
     "tmi_cast_bf16": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp]),
@@ -116,7 +116,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 _lib = None
 
 

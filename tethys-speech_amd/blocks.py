@@ -260,6 +260,39 @@ class KernelBlocks:
         for t in tensors:
             self._wait_events(self._pop_side_reads(t))
 
+    # -- the optimizer's LATE slice (optim.Adam.apply_gradients(late=...)): the part of the update whose parameters the next
+    # step reads late in its forward runs on the second stream while that step has already started; the step's first
+    # reader on the main stream waits for it (``_wait_late``), everything the step puts on the second stream is ordered
+    # behind it by the stream itself.
+    _late_ev = None
+
+    def run_late(self, fn):
+        if self._side is None:
+            fn()
+            return
+        main = self._main or torch.cuda.current_stream(self.device)
+        ev = self._event()
+        ev.record(main)                      # every gradient is final on the main stream here (backward joined the streams)
+        self._side.wait_event(ev)
+        prev = ops.set_stream(self._side_handle)
+        try:
+            fn()
+        finally:
+            ops.set_stream(prev)
+        if self.__dict__.get("_late_done") is None:
+            self._late_done = torch.cuda.Event()   # its own event, never a ring slot: it is waited for a whole encoder later
+        self._late_done.record(self._side)
+        self._late_ev = self._late_done
+
+    def _wait_late(self):
+        """Order the main stream behind the pending late slice (no-op without one).  Called before the first main-stream
+        access to what the slice updates; ``finish_late`` is the same thing for callers outside a step."""
+        if self._late_ev is not None:
+            (self._main or torch.cuda.current_stream(self.device)).wait_event(self._late_ev)
+            self._late_ev = None
+
+    finish_late = _wait_late
+
     def gradient_streams(self):
         """Streams other than the compute stream on which gradient-producing kernels are queued."""
         self._flush_deferred()

@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ 
 extern "C" int tmi_adam_step_segments(float* p, float* g, float* m, float* v, const int64_t* chunks, int64_t nchunks,
                                       const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr, float beta1, float beta2,
                                       float eps, int32_t step, int32_t eps_mode, float weight_decay, float gscale,
-                                      void* bf16_mirror, int32_t zero_grad, void* stream) {
-  if (!p || !g || !m || !v || !chunks || nchunks <= 0 || nseg <= 0 || step <= 0 || (eps_mode != 0 && eps_mode != 1) ||
+                                      void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream) {
+  if (!p || !g || !m || !v || !chunks || nchunks <= 0 || nseg <= 0 || step <= 0 || max_blocks < 0 || (eps_mode != 0 && eps_mode != 1) ||
       ((clip_global > 0.f || clip_each > 0.f) && !sumsq) || clip_global < 0.f || clip_each < 0.f || !al16(p) || !al16(g) ||
       !al16(m) || !al16(v) || (bf16_mirror && (reinterpret_cast<uintptr_t>(bf16_mirror) & 7))) {
     tmi_set_error("tmi_adam_step_segments: bad argument");
@@ -353,7 +353,9 @@ extern "C" int tmi_adam_step_segments(float* p, float* g, float* m, float* v, co
   }
   const float decay = 1.0f - lr * weight_decay;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  dim3 grid((unsigned)(nchunks < 1024 ? nchunks : 1024));
+  int64_t nblocks = nchunks < 1024 ? nchunks : 1024;
+  if (max_blocks > 0 && nblocks > max_blocks) nblocks = max_blocks;  // a throttled grid for a slice that runs beside other work
+  dim3 grid((unsigned)nblocks);
   if (zero_grad)
     hipLaunchKernelGGL(adam_segments_kernel<true>, grid, dim3(256), 0, s, p, g, m, v, chunks, nchunks, sumsq, (int)nseg, clip_global,
                        clip_each, beta1, beta2, eps, step_size, vcorr_inv_sqrt, eps_mode, decay, gscale, (bf16_t*)bf16_mirror);

@@ -382,11 +382,13 @@ def segment_chunks(seg_off, chunk=8192, device=None):
 
 
 def adam_step_segments(p, g, m, v, n, chunks, sumsq, nseg, clip_global, clip_each, lr, beta1, beta2, eps, step, eps_mode=0,
-                       weight_decay=0.0, gscale=1.0, mirror=None, zero_grad=False):
+                       weight_decay=0.0, gscale=1.0, mirror=None, zero_grad=False, max_blocks=0):
+    """``chunks`` may be a row range of the model's table (absolute arena offsets): the same update, restricted to those rows;
+    ``n`` = the elements they cover (probe accounting only)."""
     with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * n):
         check(lib().tmi_adam_step_segments(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), chunks.data_ptr(),
                                            chunks.shape[0], ptr(sumsq), nseg, clip_global, clip_each, lr, beta1, beta2, eps, step, eps_mode,
-                                           weight_decay, gscale, ptr(mirror), 1 if zero_grad else 0, stream()),
+                                           weight_decay, gscale, ptr(mirror), 1 if zero_grad else 0, max_blocks, stream()),
               "tmi_adam_step_segments")
 
 

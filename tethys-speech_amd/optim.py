@@ -27,28 +27,47 @@ class Adam:
         self.iterations = 0
         self.row_sparse = True  # embedding tables through tmi_adam_step_rows (idle rows skipped; same result bit for bit)
 
-    def apply_gradients(self, model, strategy=None, grad_scale=1.0, zero_grad=False):
+    def apply_gradients(self, model, strategy=None, grad_scale=1.0, zero_grad=False, late=None):
         """``zero_grad``: the kernel leaves the gradient arena zeroed (``arena.g_clean``), so the next
         ``forward_backward`` skips its fill pass; callers that still want to look at the gradients pass False.
-        After ``begin_early`` only the ranges no early slice has updated are left to do (same step count)."""
+        After ``begin_early`` only the ranges no early slice has updated are left to do (same step count).
+        ``late`` = (lo, hi): that arena range is updated on the model's second stream (``model.run_late``) and this call
+        returns without waiting for it - the caller promises that the next thing to touch those parameters is the next
+        step's forward (which waits, ``KernelBlocks._wait_late``) or comes after ``model.finish_late()``.  Whisper: the
+        decoder layers, 26 % of the small-ref parameters, whose first reader is a whole encoder forward away."""
         a = model.arena
         if strategy is not None:
             strategy.all_reduce_gradients(a.g)
         early, self._early = self.__dict__.get("_early"), None
         if early is None:
             self.iterations += 1
-            self._update(model, 0, a.numel, grad_scale, zero_grad, 0)
+            todo = [(0, a.numel)]
         else:
             if not zero_grad:
                 raise ValueError("early Adam slices zero their gradients: finish the step with zero_grad=True")
-            pos = 0
+            todo, pos = [], 0
             for lo, hi in sorted(early):
                 if lo > pos:
-                    self._update(model, pos, lo, grad_scale, zero_grad, 0)
+                    todo.append((pos, lo))
                 pos = max(pos, hi)
             if pos < a.numel:
-                self._update(model, pos, a.numel, grad_scale, zero_grad, 0)
+                todo.append((pos, a.numel))
+        if late is not None and not zero_grad:
+            raise ValueError("a late Adam slice zeroes its gradients behind the caller's back: zero_grad=True")
+        for lo, hi in todo:
+            if late is None or hi <= late[0] or lo >= late[1]:
+                self._update(model, lo, hi, grad_scale, zero_grad, 0)
+                continue
+            l0, l1 = max(lo, late[0]), min(hi, late[1])
+            if lo < l0:
+                self._update(model, lo, l0, grad_scale, zero_grad, 0)
+            if l1 < hi:
+                self._update(model, l1, hi, grad_scale, zero_grad, 0)
+            model.run_late(lambda l0=l0, l1=l1: self._update(model, l0, l1, grad_scale, zero_grad, self.LATE_BLOCKS))
         a.g_clean = bool(zero_grad)
+
+    # grid of the late slice: it runs beside the next step's first kernels (0 = full width)
+    LATE_BLOCKS = int(os.environ.get("TMI_ADAM_LATE_BLOCKS", "128"))
 
     def begin_early(self, model, grad_scale=1.0):
         """Start this step's update before backward has finished: returns ``update(lo, hi)``, which runs Adam on the arena
@@ -127,16 +146,29 @@ class Adam:
         a.adam_state_dirty = True
 
     def apply_gradients_clipped(self, model, chunks, sumsq, nseg, clip_global=0.0, clip_each=0.0, grad_scale=1.0,
-                                zero_grad=False):
+                                zero_grad=False, late_row=None):
         """Adam with V:1243's global-norm clip and / or V:1274's per-variable clipnorm folded into the kernel as a factor
         of g (``sumsq``: per-variable sums of squares of the raw gradients, ops.segment_sumsq; ``chunks``: ops.segment_chunks of
         the variables' offsets): no clipped copy of the
         gradient arena is written or re-read."""
         a = model.arena
         self.iterations += 1
-        ops.adam_step_segments(a.p, a.g, a.m, a.v, a.numel, chunks, sumsq, nseg, clip_global, clip_each, self.learning_rate,
-                               self.beta_1, self.beta_2, self.epsilon, self.iterations, self.eps_mode, self.weight_decay,
-                               grad_scale, mirror=model.mirror, zero_grad=zero_grad)
+
+        def rows(tab, n, blocks):
+            ops.adam_step_segments(a.p, a.g, a.m, a.v, n, tab, sumsq, nseg, clip_global, clip_each, self.learning_rate,
+                                   self.beta_1, self.beta_2, self.epsilon, self.iterations, self.eps_mode, self.weight_decay,
+                                   grad_scale, mirror=model.mirror, zero_grad=zero_grad, max_blocks=blocks)
+        if late_row is None:
+            rows(chunks, a.numel, 0)
+        else:
+            # ``late_row`` = (row index, first arena offset of that row): the rows from there on are the LATE slice (see
+            # apply_gradients): same launch arguments - the global norm comes from the whole ``sumsq`` - on the model's
+            # second stream, not waited for here
+            if not zero_grad:
+                raise ValueError("a late Adam slice zeroes its gradients behind the caller's back: zero_grad=True")
+            k, off = late_row
+            rows(chunks[:k], off, 0)
+            model.run_late(lambda: rows(chunks[k:], a.numel - off, self.LATE_BLOCKS))
         a.g_clean = bool(zero_grad)
 
     # -- the update bucket by bucket under backward -------------------------------------------------------------

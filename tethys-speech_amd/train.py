@@ -24,11 +24,21 @@ ADAM_UNDER_BACKWARD = os.environ.get("TMI_ADAM_UNDER_BACKWARD", "0") != "0"
 ADAM_EARLY = os.environ.get("TMI_ADAM_EARLY", "1") != "0"
 
 
-def distributed_train_step(strategy, model, dist_inputs, optimizer):
+# The decoder layers' share of the update (26 % of small-ref) on the second stream UNDER THE NEXT STEP's encoder forward
+# (optim.Adam.apply_gradients(late=...)).  Only for callers that say the next thing they do is another step
+# (``pipelined=True``: the training loops and the bench), one replica; TMI_ADAM_LATE=0 switches it off.
+ADAM_LATE = os.environ.get("TMI_ADAM_LATE", "1") != "0"
+
+
+def distributed_train_step(strategy, model, dist_inputs, optimizer, pipelined=False):
     """W:819-848.  Per replica: forward, backward, apply_gradients (all-reduce SUM, then
     Adam); returns ``strategy.reduce(SUM, per_replica_loss)`` as a 1-element device tensor.
-    A replica whose slice of a short final batch is empty contributes zero gradients."""
+    A replica whose slice of a short final batch is empty contributes zero gradients.
+    ``pipelined``: the caller's next access to the model is another step or ``model.finish_late()`` - the decoder layers'
+    Adam slice may then still be running on the second stream when this returns."""
     features, labels = dist_inputs
+    if hasattr(model, "finish_late") and features.shape[0] == 0:
+        model.finish_late()  # (no forward to do the waiting)
     strategy.begin_gradients(model.arena.g)
     # weight gradients run on the model's second stream: the exchange waits for it directly (the compute stream,
     # busy with the dgrad chain, is not joined to it)
@@ -49,7 +59,10 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer):
     if overlapped:
         optimizer.finish_overlapped(model, strategy)
     else:
-        optimizer.apply_gradients(model, strategy, zero_grad=True)
+        late = None
+        if pipelined and ADAM_LATE and early is not None and hasattr(model, "late_adam_range"):
+            late = model.late_adam_range()
+        optimizer.apply_gradients(model, strategy, zero_grad=True, late=late)
     return strategy.reduce_sum(loss.clone())
 
 
@@ -177,7 +190,7 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
         for _ in range(num_batches):
             inputs = next(it)
             step_start = time.time()
-            loss = distributed_train_step(strategy, model, inputs, optimizer)
+            loss = distributed_train_step(strategy, model, inputs, optimizer, pipelined=True)
             # the reference's loss.numpy() (W:951), fetched behind an event so the next step is enqueued meanwhile
             emit(fetch.push(loss, (step, step_start)))
             step += 1
@@ -193,6 +206,8 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
     # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
     # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
     wait_for_checkpoints()
+    if hasattr(model, "finish_late"):
+        model.finish_late()  # whoever looks at the model next does so after its last update
     model.losses = losses
     return model
 
@@ -268,6 +283,8 @@ def save_checkpoint(model, optimizer, path, dataset=None, step=None, background=
     ``background``: snapshot p / m / v on the device (stream-ordered after the last update, ~2 ms) and let a thread do the
     device-to-host copy and the file write: the 1.8 GB dump otherwise is 0.7 s of a short job's JCT (``wait_for_checkpoints``)."""
     a = model.arena
+    if hasattr(model, "finish_late"):
+        model.finish_late()  # a decoder-layer Adam slice left running by a pipelined step: the snapshot comes after it
     meta = {"iterations": optimizer.iterations, "names": a.names, "offsets": a.offsets, "shapes": a.shapes,
             "drop_step": int(getattr(model, "_drop_step", 0)),
             "data_pos": None if dataset is None else int(dataset._pos),
@@ -294,6 +311,8 @@ def load_checkpoint(model, optimizer, path, dataset=None):
     """The restore path the reference lacks.  Returns the step index to continue from."""
     ck = torch.load(path, map_location="cpu")
     a = model.arena
+    if hasattr(model, "finish_late"):
+        model.finish_late()
     if ck["names"] != a.names or ck["offsets"] != a.offsets or ck["shapes"] != a.shapes or ck["p"].numel() != a.p.numel():
         raise ValueError("checkpoint layout does not match the model")
     a.p.copy_(ck["p"]); a.m.copy_(ck["m"]); a.v.copy_(ck["v"])
@@ -309,7 +328,7 @@ def load_checkpoint(model, optimizer, path, dataset=None):
 # ---------------------------------------------------------------------------------------
 # Wav2Vec2 (speech_jobs/wav2vec2_dist.py, "V:")
 # ---------------------------------------------------------------------------------------
-def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
+def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer, pipelined=False):
     """V:1186-1260.  Per replica: forward, loss / num_replicas, backward, LOCAL
     clip_by_global_norm(1.0) (V:1243, before the exchange), gradient all-reduce SUM (=> mean),
     Keras clipnorm(1.0) per variable (V:1274, after aggregation), Adam; returns
@@ -319,6 +338,7 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
     if audio.shape[0] > 0:
         loss = model.forward_backward(audio, neg_indices, num_replicas=strategy.num_replicas_in_sync)
     else:  # the reference's empty-batch branch (V:1196-1198, V:1250-1254)
+        model.finish_late()
         a.g.zero_()
         loss = torch.zeros(1, dtype=torch.float32, device=model.device)
     model._prepare_clip()
@@ -328,8 +348,11 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer):
         # global norm is their sum) feeds an Adam launch that applies c_global * c_variable on the fly
         if audio.shape[0] > 0:
             ops.segment_sumsq_chunks(a.g, model.seg_chunks, ws["clip_vars"], model.n_var)
+            # ``pipelined`` (the caller's next access to the model is another step or model.finish_late()): the slice of the
+            # update from encoder layer L/6 on runs on the second stream under the next step's conv stack and first layers
+            late = model._late_row if (pipelined and ADAM_LATE and model._side is not None) else None
             optimizer.apply_gradients_clipped(model, model.seg_chunks, ws["clip_vars"], model.n_var, clip_global=1.0,
-                                              clip_each=1.0, zero_grad=True)
+                                              clip_each=1.0, zero_grad=True, late_row=late)
         else:
             optimizer.apply_gradients(model, None, zero_grad=True)
     else:
@@ -393,7 +416,7 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             neg_all = sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
             neg = torch.from_numpy(neg_all[strategy.rank * batch_size:(strategy.rank + 1) * batch_size]).to(device)
             step_start = time.time()
-            loss = wav2vec2_train_step(strategy, model, audio, neg, optimizer)
+            loss = wav2vec2_train_step(strategy, model, audio, neg, optimizer, pipelined=True)
             emit(fetch.push(loss, (step, step_start)))
             step += 1
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
@@ -409,6 +432,7 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
     # the reference's checkpoint.save sits inside this function (W:916-919, V:1341-1342), i.e. inside the job's JCT window:
     # mid-run writes overlap training, the last one is waited for here, before the caller reads its clock
     wait_for_checkpoints()
+    model.finish_late()  # whoever looks at the model next does so after its last update
     model.losses = losses
     return model
 

@@ -176,6 +176,22 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self.seg_vars = so.to(self.device)
         self.seg_chunks = ops.segment_chunks(so, device=self.device)  # the table Adam-with-clipping walks
         self.seg_all = torch.tensor([0, self.arena.numel], dtype=torch.int64, device=self.device)
+        # The LATE slice of the clipped Adam update (train.ADAM_LATE, optim.Adam.apply_gradients_clipped(late_row=...)): the
+        # arena from encoder layer L/6 to the end (the layers above it and project_hid, which follows them in the arena and
+        # in the forward) - 77 % of the base model, first read a conv stack and L/6 layers into the next step.  Measured
+        # (ms/step, two rounds on one box, 128 workgroups): from layer 2 4.66 / 4.58, 4: 4.71 / 4.63, 6: 4.73 / 4.63,
+        # 8: 4.69 / 4.67; off: 4.74; 192 workgroups lose 0.05-0.07 everywhere, 64 do not finish in time (+0.09).
+        Lh = config.num_hidden_layers
+        self._late_first = max(1, int(os.environ.get("TMI_ADAM_LATE_LAYER", Lh // 6))) if Lh >= 3 else None
+        if self._late_first is not None and self._late_first >= Lh:
+            self._late_first = None
+        self._late_row = None
+        if self._late_first is not None:
+            pre = f"encoder.layers.{self._late_first}."
+            off = min(o for n, o in self.arena.offsets.items() if n.startswith(pre))
+            rows = [i for i, (lo, _, _) in enumerate(self.seg_chunks.tolist()) if lo >= off]
+            if rows and int(self.seg_chunks[rows[0], 0]) == off:
+                self._late_row = (rows[0], off)
         self.refresh_shadows()
         # weight / bias gradients on a second stream beside the dgrad chain (blocks.KernelBlocks): 6.03 -> 5.9 ms
         self.enable_wgrad_stream(os.environ.get("TMI_WGRAD_STREAM", "1") != "0")
@@ -342,6 +358,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         hd = H // Hh
         sscale = 1.0 / math.sqrt(hd)
         if not getattr(a, "g_clean", False):
+            self._wait_late()  # (a pending late Adam slice reads the gradients this fill would overwrite)
             a.g.zero_()
         a.g_clean = False
 
@@ -412,6 +429,8 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         for i in range(cfg.num_hidden_layers):
             p, kk = f"encoder.layers.{i}", f"enc{i}."
             x_in = ws[kk + "x_in"]
+            if i == self._late_first:
+                self._wait_late()  # the previous step's Adam slice for this layer and everything after it, if left running
             self._ln_fwd(x_in, p + ".attention_layer_norm", ws[kk + "xn1"], kk + "ln1")
             wq, _ = self.W(p + ".attention.qkv3.kernel")  # [3H, H] view of the three blocks
             ops.gemm(ws[kk + "xn1"], wq, ws[kk + "qkv"], R, H, H, H, 1, H, 1, 3 * H, nbatch=3, b_sb=H * H, c_sb=H,

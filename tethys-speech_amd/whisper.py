@@ -364,6 +364,15 @@ class WhisperForConditionalGeneration(KernelBlocks):
                 hi = lo
 
     # -- forward -------------------------------------------------------------------------
+    def late_adam_range(self):
+        """Arena range whose first reader in a step is the decoder, a whole encoder forward after the step began: the
+        cross-attention k/v projection, the decoder layers and the decoder's final LayerNorm (the embedding table before
+        it and the LM head after it are the EARLY slices).  None when there is no such range (no decoder layers)."""
+        a = self.arena
+        if not self.config.decoder_layers or "decoder.cross_kv.kernel" not in a.offsets:
+            return None
+        return a.offsets["decoder.cross_kv.kernel"], a.offsets["lm_head.kernel"]
+
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
                          grad_ready=None, early_update=None):
         """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
@@ -398,6 +407,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         T, He, Hd = self.T, cfg.encoder_attention_heads, cfg.decoder_attention_heads
         scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
         if not getattr(a, "g_clean", False):
+            self._wait_late()  # (a pending late Adam slice reads the gradients this fill would overwrite)
             a.g.zero_()  # (an optimizer step with zero_grad leaves the arena clean: no fill pass)
         a.g_clean = False
         done = [a.numel]
@@ -502,6 +512,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         enc_out = ws["enc_out"]
 
         # ---- decoder (W:394-466)
+        self._wait_late()  # the previous step's decoder-layer Adam slice, if it was left running (train.ADAM_LATE)
         if not early_dec:
             dec_embed()
         if Ld:
