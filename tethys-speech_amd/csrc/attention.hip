@@ -674,22 +674,37 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
       f32x16 dp = first_product(Oimg, 32 * rbk, vf, c, h);  // dp[q][key]
       f32x16 ds;
       if constexpr (!edge) {
+        // Dropout draws: the pair hash of (query row, key >> 1) is the SAME number in the two lanes of a key pair (the even
+        // key takes its low half, the odd key the high half), so each lane computes it for half of its 16 query rows -
+        // the even lane for accumulator registers 0..7, the odd lane for 8..15 - and the pair swaps through DPP
+        // (quad_perm): 8 hashes + 16 cross-lane moves per lane instead of 16 hashes.
+        uint32_t hx[DROP ? 8 : 1];
+        if constexpr (DROP) {
+          const int odd = lane & 1;
+#pragma unroll
+          for (int jg = 0; jg < 2; ++jg) {
+            const int r = 32 * rbk + 8 * (jg + 2 * odd) + 4 * h;  // rows of registers 4 jg + 8 odd .. + 3
+            const f32x4 ra4 = *reinterpret_cast<const f32x4*>(rowc + 256 + r);
+            const f32x4 rb4 = *reinterpret_cast<const f32x4*>(rowc + 320 + r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              hx[4 * jg + i] = tmi_pair_hash(tmi_rowkey{__float_as_uint(ra4[i]), __float_as_uint(rb4[i])}, khalf);
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r = 32 * rbk + 8 * g + 4 * h;
           const f32x4 nM = *reinterpret_cast<const f32x4*>(rowc + 192 + r);
           const f32x4 dl = *reinterpret_cast<const f32x4*>(rowc + 128 + r);
-          f32x4 ra4 = f32x4{0.f, 0.f, 0.f, 0.f}, rb4 = ra4;
-          if constexpr (DROP) {
-            ra4 = *reinterpret_cast<const f32x4*>(rowc + 256 + r);
-            rb4 = *reinterpret_cast<const f32x4*>(rowc + 320 + r);
-          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * g + i;
             const float pe = ex2(fmaf(s[e], c2, nM[i]));
             if constexpr (DROP) {  // dV sees the dropped probabilities, dS the masked dP: ds = p * (mask/keep * dp - delta)
-              const bool keep = keep_at(ra4[i], rb4[i]);
+              // registers 0..7: the even lane's hash (quad_perm [0,0,2,2] = 0xA0); 8..15: the odd lane's ([1,1,3,3] = 0xF5)
+              const uint32_t hh = e < 8 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hx[e & 7], 0xA0, 0xF, 0xF, false)
+                                        : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hx[e & 7], 0xF5, 0xF, 0xF, false);
+              const bool keep = ((hh >> ksh) & 0xffffu) >= drop_thr;
               s[e] = keep ? pe : 0.f;
               ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - dl[i]);
             } else {
