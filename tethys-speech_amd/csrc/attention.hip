@@ -535,6 +535,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
         if constexpr (DROP) return ((e & 1) ? (hh >> 16) : (hh & 0xffffu)) < drop_thr ? 0.f : dp[e] * keep_scale;
         else return dp[e];
       };
+      // d(p) - delta with the mask as a factor of an fma (select on the constant, not on the product)
+      auto dpm_minus = [&](int e, uint32_t hh, float dl_) -> float {
+        if constexpr (DROP) return fmaf(dp[e], ((e & 1) ? (hh >> 16) : (hh & 0xffffu)) < drop_thr ? 0.f : keep_scale, -dl_);
+        else return dp[e] - dl_;
+      };
       auto pair_draw = [&](int e) -> uint32_t {  // e even
         if constexpr (DROP) return tmi_pair_hash(qrk, (uint32_t)((key0 + 32 * rbk + 8 * (e >> 2) + 4 * h) >> 1) + ((e >> 1) & 1));
         else return 0u;
@@ -543,8 +548,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
           const uint32_t hh = pair_draw(e);
-          s[e] = ex2(fmaf(s[e], c2, nM)) * (dpm(e, hh) - delta);  // dS
-          s[e + 1] = ex2(fmaf(s[e + 1], c2, nM)) * (dpm(e + 1, hh) - delta);
+          s[e] = ex2(fmaf(s[e], c2, nM)) * dpm_minus(e, hh, delta);  // dS
+          s[e + 1] = ex2(fmaf(s[e + 1], c2, nM)) * dpm_minus(e + 1, hh, delta);
         }
       } else {
 #pragma unroll
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
                                         : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hx[e & 7], 0xF5, 0xF, 0xF, false);
               const bool keep = ((hh >> ksh) & 0xffffu) >= drop_thr;
               s[e] = keep ? pe : 0.f;
-              ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - dl[i]);
+              ds[e] = pe * fmaf(dp[e], keep ? keep_scale : 0.f, -dl[i]);  // (select on the constant: one op fewer than on the product)
             } else {
               s[e] = pe;
               ds[e] = pe * (dp[e] - dl[i]);
