@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   const float keep_scale = P.keep_scale;
   const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
   const uint32_t khalf = (uint32_t)key >> 1, ksh = ((uint32_t)key & 1u) * 16u;
+  const uint32_t lane_mask = 0xffffu << ksh, lane_thr = drop_thr << ksh;  // this key's half of a pair hash, in place
   auto keep_at = [&](float ra, float rb) -> bool {  // this lane's key against the query row whose mask-row key is (ra, rb)
     const uint32_t hh = tmi_pair_hash(tmi_rowkey{__float_as_uint(ra), __float_as_uint(rb)}, khalf);
     return ((hh >> ksh) & 0xffffu) >= drop_thr;
@@ -706,10 +707,17 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
             const int e = 4 * g + i;
             const float pe = ex2(fmaf(s[e], c2, nM[i]));
             if constexpr (DROP) {  // dV sees the dropped probabilities, dS the masked dP: ds = p * (mask/keep * dp - delta)
-              // registers 0..7: the even lane's hash (quad_perm [0,0,2,2] = 0xA0); 8..15: the odd lane's ([1,1,3,3] = 0xF5)
-              const uint32_t hh = e < 8 ? (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hx[e & 7], 0xA0, 0xF, 0xF, false)
-                                        : (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hx[e & 7], 0xF5, 0xF, 0xF, false);
-              const bool keep = ((hh >> ksh) & 0xffffu) >= drop_thr;
+              // registers 0..7: the even lane's hash (quad_perm [0,0,2,2]); 8..15: the odd lane's ([1,1,3,3]).  The swap is
+              // the DPP operand of the AND that cuts this lane's 16 bits out of the 32 (low half for the even key, high
+              // half - left in place, compared with the threshold shifted likewise - for the odd one): one instruction
+              // instead of move + bit-field extract.  (s_nop: a DPP read needs two wait states after the VALU write of
+              // its source, and the hazard recogniser does not look inside asm.)
+              uint32_t cut;
+              if (e < 8)
+                asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "=v"(cut) : "v"(hx[e & 7]), "v"(lane_mask));
+              else
+                asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "=v"(cut) : "v"(hx[e & 7]), "v"(lane_mask));
+              const bool keep = cut >= lane_thr;
               s[e] = keep ? pe : 0.f;
               ds[e] = pe * fmaf(dp[e], keep ? keep_scale : 0.f, -dl[i]);  // (select on the constant: one op fewer than on the product)
             } else {

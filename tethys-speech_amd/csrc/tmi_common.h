@@ -99,7 +99,11 @@ __host__ __device__ __forceinline__ tmi_rowkey tmi_row_key(uint32_t stream_key, 
 // 32 bits for column pair `cp` (= column >> 1) of the row with key `rk`
 __host__ __device__ __forceinline__ uint32_t tmi_pair_hash(tmi_rowkey rk, uint32_t cp) {
   uint32_t h = tmi_mul24(rk.a ^ cp, 0x9E3779u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  h = __builtin_amdgcn_bitop3_b32(h, h >> 15, rk.b, 0x96);  // the same three-way XOR as ONE v_bitop3_b32 (truth table 0x96); hipcc emits two v_xor
+#else
   h = h ^ (h >> 15) ^ rk.b;
+#endif
   return tmi_mul24(h, 0x85EBCBu);
 }
 __host__ __device__ __forceinline__ uint32_t tmi_drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
