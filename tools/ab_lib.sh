@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 L=tethys-speech_amd/libtethys_mi.so
 cp abx/lib_new.so $L
-python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attention or flash or dropout" > gpurun_out/ab_lib_tests.log 2>&1 || { tail -30 gpurun_out/ab_lib_tests.log; exit 1; }
+python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attention or flash or dropout or layernorm" > gpurun_out/ab_lib_tests.log 2>&1 || { tail -30 gpurun_out/ab_lib_tests.log; exit 1; }
 tail -1 gpurun_out/ab_lib_tests.log
 for which in old new old new; do
   cp abx/lib_$which.so $L
