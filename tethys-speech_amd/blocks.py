@@ -264,9 +264,9 @@ class KernelBlocks:
     # step reads late in its forward runs on the second stream while that step has already started; the step's first
     # reader on the main stream waits for it (``_wait_late``), everything the step puts on the second stream is ordered
     # behind it by the stream itself.
-    _late_ev = None
+    _late_ev = None      # truthy while some late slice may still be running (tests look at it)
 
-    def run_late(self, fn):
+    def run_late(self, fn, key="late"):
         if self._side is None:
             fn()
             return
@@ -279,19 +279,31 @@ class KernelBlocks:
             fn()
         finally:
             ops.set_stream(prev)
-        if self.__dict__.get("_late_done") is None:
-            self._late_done = torch.cuda.Event()   # its own event, never a ring slot: it is waited for a whole encoder later
-        self._late_done.record(self._side)
-        self._late_ev = self._late_done
+        evs = self.__dict__.setdefault("_late_done", {})
+        if key not in evs:
+            evs[key] = torch.cuda.Event()    # its own event, never a ring slot: it is waited for a whole encoder later
+        evs[key].record(self._side)
+        pend = self.__dict__.setdefault("_late_pending", {})
+        pend[key] = evs[key]
+        self._late_ev = pend
 
-    def _wait_late(self):
-        """Order the main stream behind the pending late slice (no-op without one).  Called before the first main-stream
-        access to what the slice updates; ``finish_late`` is the same thing for callers outside a step."""
-        if self._late_ev is not None:
-            (self._main or torch.cuda.current_stream(self.device)).wait_event(self._late_ev)
+    def _wait_late(self, key=None):
+        """Order the main stream behind the pending late slice ``key`` (behind all of them without a key); no-op when
+        nothing is pending.  Called before the first main-stream access to what a slice updates; ``finish_late`` is the
+        same thing for callers outside a step."""
+        pend = self.__dict__.get("_late_pending")
+        if not pend:
+            return
+        main = self._main or torch.cuda.current_stream(self.device)
+        for k in ([key] if key is not None else list(pend)):
+            ev = pend.pop(k, None)
+            if ev is not None:
+                main.wait_event(ev)
+        if not pend:
             self._late_ev = None
 
-    finish_late = _wait_late
+    def finish_late(self):
+        self._wait_late()
 
     def gradient_streams(self):
         """Streams other than the compute stream on which gradient-producing kernels are queued."""

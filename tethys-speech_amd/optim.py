@@ -31,8 +31,8 @@ class Adam:
         """``zero_grad``: the kernel leaves the gradient arena zeroed (``arena.g_clean``), so the next
         ``forward_backward`` skips its fill pass; callers that still want to look at the gradients pass False.
         After ``begin_early`` only the ranges no early slice has updated are left to do (same step count).
-        ``late`` = (lo, hi): that arena range is updated on the model's second stream (``model.run_late``) and this call
-        returns without waiting for it - the caller promises that the next thing to touch those parameters is the next
+        ``late`` = (lo, hi) or [(lo, hi, key), ...]: those arena ranges are updated on the model's second stream
+        (``model.run_late``) and this call returns without waiting for them - the caller promises that the next thing to touch those parameters is the next
         step's forward (which waits, ``KernelBlocks._wait_late``) or comes after ``model.finish_late()``.  Whisper: the
         decoder layers, 26 % of the small-ref parameters, whose first reader is a whole encoder forward away."""
         a = model.arena
@@ -52,18 +52,32 @@ class Adam:
                 pos = max(pos, hi)
             if pos < a.numel:
                 todo.append((pos, a.numel))
-        if late is not None and not zero_grad:
+        if late and not zero_grad:
             raise ValueError("a late Adam slice zeroes its gradients behind the caller's back: zero_grad=True")
-        for lo, hi in todo:
-            if late is None or hi <= late[0] or lo >= late[1]:
+        # ``late``: (lo, hi) or a list of (lo, hi, key) in the order the next step will need them
+        if late and not isinstance(late[0], (tuple, list)):
+            late = [(late[0], late[1], "late")]
+        pieces = [(lo, hi, None) for lo, hi in todo]
+        for l_lo, l_hi, key in (late or []):
+            cut = []
+            for lo, hi, k in pieces:
+                if k is not None or hi <= l_lo or lo >= l_hi:
+                    cut.append((lo, hi, k))
+                    continue
+                if lo < l_lo:
+                    cut.append((lo, l_lo, None))
+                cut.append((max(lo, l_lo), min(hi, l_hi), key))
+                if l_hi < hi:
+                    cut.append((l_hi, hi, None))
+            pieces = cut
+        for lo, hi, k in pieces:          # what the next step reads first: now, on this stream
+            if k is None:
                 self._update(model, lo, hi, grad_scale, zero_grad, 0)
-                continue
-            l0, l1 = max(lo, late[0]), min(hi, late[1])
-            if lo < l0:
-                self._update(model, lo, l0, grad_scale, zero_grad, 0)
-            if l1 < hi:
-                self._update(model, l1, hi, grad_scale, zero_grad, 0)
-            model.run_late(lambda l0=l0, l1=l1: self._update(model, l0, l1, grad_scale, zero_grad, self.LATE_BLOCKS))
+        for _, _, key in (late or []):    # the rest on the model's second stream, in the order given
+            mine = [(lo, hi) for lo, hi, k in pieces if k == key]
+            if mine:
+                model.run_late(lambda mine=mine: [self._update(model, lo, hi, grad_scale, zero_grad, self.LATE_BLOCKS)
+                                                  for lo, hi in mine], key)
         a.g_clean = bool(zero_grad)
 
     # grid of the late slice: it runs beside the next step's first kernels (0 = full width)
