@@ -89,6 +89,11 @@ typedef struct tmi_gemm_desc {
    * C = resid + (keep ? v / (1 - p) : 0) with the generator of tmi_dropout over the [M, N] output (row m, column n; N <= 2^17).
    * dropout_p == 0 is off.  nbatch must be 1. */
   float dropout_p; uint64_t dropout_seed;
+  /* A second, OUTER batch level (0 / 1 = none): problem z = b2 * nbatch + b1 reads A + b1*a_sb + b2*a_sb2 (likewise B, C).
+   * For operands whose two batch indices are not one stride apart - per-(sample, head) products on [B, T, H*hd] tensors
+   * (W:147-167 in the fp32 parity mode: one launch instead of one per sample).  Only with plain epilogues (scale /
+   * accumulate), nbatch * nbatch2 <= 65535; never on the bf16 fast path. */
+  int64_t nbatch2, a_sb2, b_sb2, c_sb2;
 } tmi_gemm_desc;
 int tmi_gemm(const tmi_gemm_desc* d, void* stream);
 

@@ -119,6 +119,32 @@ def test_gemm_conv_addressing(dev, dtype):
         assert rel_err(y, ref) <= tol(dtype) * 4
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_two_batch_levels(dev, dtype):
+    """tmi_gemm_desc.nbatch2: per-(sample, head) products on [B, T, H*hd] tensors in one launch (the fp32 parity mode's
+    q.k^T of W:147-153): heads are the inner batch level (stride hd inside a token row), samples the outer one."""
+    ops = _ops()
+    B, H, Tq, Tk, hd = 3, 4, 70, 150, 64
+    D = H * hd
+    q = rnd((B, Tq, D), dtype, dev, 61)
+    k = rnd((B, Tk, D), dtype, dev, 62)
+    P = torch.full((B, H, Tq, Tk), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(q, k, P, Tq, Tk, hd, D, 1, 1, D, Tk, nbatch=H, a_sb=hd, b_sb=hd, c_sb=Tq * Tk, scale_cols=Tk, scale=0.125,
+             nbatch2=B, a_sb2=Tq * D, b_sb2=Tk * D, c_sb2=H * Tq * Tk)
+    qh = q.double().reshape(B, Tq, H, hd).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, Tk, H, hd).permute(0, 2, 1, 3)
+    ref = 0.125 * (qh @ kh.transpose(-1, -2))
+    assert rel_err(P, ref) <= tol(dtype)
+    # and back: ctx[b, t, h*hd + j] = sum_k P[b, h, t, k] v[b, k, h*hd + j]
+    v = rnd((B, Tk, D), dtype, dev, 63)
+    ctx = torch.full((B, Tq, D), float("nan"), dtype=dtype, device=dev)
+    ops.gemm(P, v, ctx, Tq, hd, Tk, Tk, 1, D, 1, D, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
+             nbatch2=B, a_sb2=H * Tq * Tk, b_sb2=Tk * D, c_sb2=Tq * D)
+    vh = v.double().reshape(B, Tk, H, hd).permute(0, 2, 1, 3)
+    refc = (P.double() @ vh).permute(0, 2, 1, 3).reshape(B, Tq, D)
+    assert rel_err(ctx, refc) <= tol(dtype)
+
+
 def test_gemm_kbatch_splitk(dev):
     """wgrad form with the reduction running over (batch, time) and split-K atomics."""
     ops = _ops()

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("in_dtype", c_i32), ("out_dtype", c_i32),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("dropout_p", c_f32), ("dropout_seed", C.c_uint64),
+        ("nbatch2", c_i64), ("a_sb2", c_i64), ("b_sb2", c_i64), ("c_sb2", c_i64),
     ]
 
 
@@ -116,7 +117,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 _lib = None
 
 

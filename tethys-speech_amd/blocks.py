@@ -518,16 +518,16 @@ class KernelBlocks:
                          self.ws[key], B, H, Tq, Tk, mask, score_scale=score_scale,
                          dropout_p=dp, dropout_seed=self._site_seed(site) if dp > 0 else 0)
             return
+        # fp32 parity mode (W:147-167 as written: scores materialised).  One launch per product over all (sample, head)
+        # pairs: heads are the inner batch level (stride hd inside a token row), samples the outer one (tmi_gemm nbatch2)
         P = self.ws[key]
         hd = d // H
-        for b in range(B):
-            ops.gemm(qt, kt, P, Tq, Tk, hd, qt.stride(0), 1, 1, kt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd,
-                     c_sb=Tq * Tk, a_off=b * Tq * qt.stride(0) + qo, b_off=b * Tk * kt.stride(0) + ko,
-                     c_off=b * H * Tq * Tk, scale_cols=Tk if score_scale != 1.0 else 0, scale=score_scale)
+        ops.gemm(qt, kt, P, Tq, Tk, hd, qt.stride(0), 1, 1, kt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd,
+                 c_sb=Tq * Tk, a_off=qo, b_off=ko, scale_cols=Tk if score_scale != 1.0 else 0, scale=score_scale,
+                 nbatch2=B, a_sb2=Tq * qt.stride(0), b_sb2=Tk * kt.stride(0), c_sb2=H * Tq * Tk)
         ops.softmax_fwd(P, B * H * Tq, Tq, Tk, mask)
-        for b in range(B):
-            ops.gemm(P, vt, ctx2d, Tq, hd, Tk, Tk, 1, vt.stride(0), 1, d, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
-                     a_off=b * H * Tq * Tk, b_off=b * Tk * vt.stride(0) + vo, c_off=b * Tq * d)
+        ops.gemm(P, vt, ctx2d, Tq, hd, Tk, Tk, 1, vt.stride(0), 1, d, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
+                 b_off=vo, nbatch2=B, a_sb2=H * Tq * Tk, b_sb2=Tk * vt.stride(0), c_sb2=Tq * d)
 
     def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask, score_scale=1.0,
                   q_prescaled=True, site=None, dkv_on_side=False):
@@ -562,23 +562,20 @@ class KernelBlocks:
             return
         P = self.ws[key]
         dP = self.ws["dP"]
-        for b in range(B):
-            po = b * H * Tq * Tk
-            # dP = dctx · Vᵀ
-            ops.gemm(dctx2d, vt, dP, Tq, Tk, hd, d, 1, 1, vt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd, c_sb=Tq * Tk,
-                     a_off=b * Tq * d, b_off=b * Tk * vt.stride(0) + vo, c_off=po)
-            # dV = Pᵀ · dctx
-            ops.gemm(P, dctx2d, dvt, Tk, hd, Tq, 1, Tk, d, 1, dvt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
-                     a_off=po, b_off=b * Tq * d, c_off=b * Tk * dvt.stride(0) + dvo)
+        PP = H * Tq * Tk  # one sample's scores
+        # dP = dctx · Vᵀ
+        ops.gemm(dctx2d, vt, dP, Tq, Tk, hd, d, 1, 1, vt.stride(0), Tk, nbatch=H, a_sb=hd, b_sb=hd, c_sb=Tq * Tk,
+                 b_off=vo, nbatch2=B, a_sb2=Tq * d, b_sb2=Tk * vt.stride(0), c_sb2=PP)
+        # dV = Pᵀ · dctx
+        ops.gemm(P, dctx2d, dvt, Tk, hd, Tq, 1, Tk, d, 1, dvt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
+                 c_off=dvo, nbatch2=B, a_sb2=PP, b_sb2=Tq * d, c_sb2=Tk * dvt.stride(0))
         ops.softmax_bwd(P, dP, B * H * Tq, Tk)
-        for b in range(B):
-            po = b * H * Tq * Tk
-            # dQ = dS · K  (then * scaling: chain rule of W:141, folded into this GEMM's column scale)
-            ops.gemm(dP, kt, dqt, Tq, hd, Tk, Tk, 1, kt.stride(0), 1, dqt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
-                     c_sb=hd, a_off=po, b_off=b * Tk * kt.stride(0) + ko, c_off=b * Tq * dqt.stride(0) + dqo,
-                     scale_cols=hd, scale=scaling)
-            # dK = dSᵀ · Q
-            # (a pre-scaled q already carries the factor; otherwise the score scale applies here too)
-            ops.gemm(dP, qt, dkt, Tk, hd, Tq, 1, Tk, qt.stride(0), 1, dkt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
-                     c_sb=hd, a_off=po, b_off=b * Tq * qt.stride(0) + qo, c_off=b * Tk * dkt.stride(0) + dko,
-                     scale_cols=0 if q_prescaled else hd, scale=score_scale)
+        # dQ = dS · K  (then * scaling: chain rule of W:141, folded into this GEMM's column scale)
+        ops.gemm(dP, kt, dqt, Tq, hd, Tk, Tk, 1, kt.stride(0), 1, dqt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
+                 c_sb=hd, b_off=ko, c_off=dqo, scale_cols=hd, scale=scaling,
+                 nbatch2=B, a_sb2=PP, b_sb2=Tk * kt.stride(0), c_sb2=Tq * dqt.stride(0))
+        # dK = dSᵀ · Q
+        # (a pre-scaled q already carries the factor; otherwise the score scale applies here too)
+        ops.gemm(dP, qt, dkt, Tk, hd, Tq, 1, Tk, qt.stride(0), 1, dkt.stride(0), nbatch=H, a_sb=Tq * Tk, b_sb=hd,
+                 c_sb=hd, b_off=qo, c_off=dko, scale_cols=0 if q_prescaled else hd, scale=score_scale,
+                 nbatch2=B, a_sb2=PP, b_sb2=Tq * qt.stride(0), c_sb2=Tk * dkt.stride(0))

@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
   const int it0 = blockIdx.y * per;
   const int it1 = min(total_it, it0 + per);
 
-  const T* Abase = reinterpret_cast<const T*>(d.A) + bz * d.a_sb;
-  const T* Bbase = reinterpret_cast<const T*>(d.B) + bz * d.b_sb;
+  // two batch levels: z = b2 * nbatch + b1 (nbatch2 <= 1: b2 = 0)
+  const int64_t b2 = d.nbatch2 > 1 ? bz / d.nbatch : 0, b1 = bz - b2 * d.nbatch;
+  const T* Abase = reinterpret_cast<const T*>(d.A) + b1 * d.a_sb + b2 * d.a_sb2;
+  const T* Bbase = reinterpret_cast<const T*>(d.B) + b1 * d.b_sb + b2 * d.b_sb2;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -205,7 +207,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams P) {
     }
   }
 
-  gemm_epilogue<TC>(d, acc, m0, n0, bz, wr, wc, lane, gridDim.y > 1);
+  if (b2 == 0) {
+    gemm_epilogue<TC>(d, acc, m0, n0, b1, wr, wc, lane, gridDim.y > 1);
+  } else {  // (outer batches carry no bias / aux / residual terms: only C moves)
+    tmi_gemm_desc dd = d;
+    dd.C = reinterpret_cast<TC*>(d.C) + b2 * d.c_sb2;
+    gemm_epilogue<TC>(dd, acc, m0, n0, b1, wr, wc, lane, gridDim.y > 1);
+  }
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -231,14 +239,14 @@ int launch(const tmi_gemm_desc& d, hipStream_t stream) {
   int splitk = d.splitk > 1 ? d.splitk : 1;
   if (d.splitk == 0 && sizeof(TC) == 4 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in && !d.resid &&
       d.scale_cols <= 0) {  // auto split-K for weight-gradient shapes, as on the fast path
-    const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch;
+    const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n * d.nbatch * (d.nbatch2 > 1 ? d.nbatch2 : 1);
     const int64_t its = (int64_t)d.kbatch * P.ktiles;
     int64_t want = (512 + tiles - 1) / tiles;
     if (want > its / 4) want = its / 4;
     if (want > 64) want = 64;
     splitk = want < 1 ? 1 : (int)want;
   }
-  dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)d.nbatch);
+  dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)(d.nbatch * (d.nbatch2 > 1 ? d.nbatch2 : 1)));
   hipLaunchKernelGGL((gemm_kernel<T, TC>), grid, dim3(256), 2 * TILE_BYTES, stream, P);
   return tmi_check_launch("tmi_gemm");
 }
@@ -264,8 +272,13 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
   }
   if (d.nbatch <= 0) d.nbatch = 1;
   if (d.kbatch <= 0) d.kbatch = 1;
-  if (d.nbatch > 65535 || d.splitk > 65535) {
+  if (d.nbatch2 <= 0) d.nbatch2 = 1;
+  if (d.nbatch * d.nbatch2 > 65535 || d.splitk > 65535) {
     tmi_set_error("tmi_gemm: nbatch/splitk exceed grid limits");
+    return TMI_ERR_INVALID;
+  }
+  if (d.nbatch2 > 1 && (d.bias || d.act || d.aux_out || d.aux_in || d.resid || d.dropout_p > 0.f)) {
+    tmi_set_error("tmi_gemm: an outer batch level (nbatch2) takes plain epilogues only");
     return TMI_ERR_INVALID;
   }
   if (d.splitk < 0) d.splitk = 1;
@@ -285,7 +298,7 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d.in_dtype == TMI_BF16 && (d.out_dtype == TMI_BF16 || d.out_dtype == TMI_F32) && !fast_disabled()) {
+  if (d.nbatch2 == 1 && d.in_dtype == TMI_BF16 && (d.out_dtype == TMI_BF16 || d.out_dtype == TMI_F32) && !fast_disabled()) {
     int rc = 0;
     if (tmi_gemm_fast_try(d, s, &rc)) return rc;
   }

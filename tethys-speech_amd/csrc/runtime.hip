@@ -19,5 +19,5 @@ int tmi_check_launch(const char* what) {
   return TMI_OK;
 }
 
-extern "C" int tmi_abi_version(void) { return 20; }
+extern "C" int tmi_abi_version(void) { return 21; }
 extern "C" const char* tmi_last_error(void) { return g_err; }

@@ -119,9 +119,9 @@ def gemm_workspace(device):
 def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
          kbatch=1, a_skb=0, b_skb=0, bias=None, bias_sb=0, scale_cols=0, scale=1.0, accumulate=False,
          act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
-         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0):
+         a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0, nbatch2=1, a_sb2=0, b_sb2=0, c_sb2=0):
     """C = epi(A·B); see tmi_gemm in include/tethys_mi.h.  ``*_off`` are element offsets
-    added to the tensors' base pointers (aux_* share c_off)."""
+    added to the tensors' base pointers (aux_* share c_off).  ``nbatch2`` / ``*_sb2``: an outer batch level."""
     d = GemmDesc()
     esA, esC = A.element_size(), Cm.element_size()
     d.A = A.data_ptr() + a_off * esA
@@ -142,6 +142,7 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     d.r_ld, d.r_sb = r_ld, r_sb
     d.splitk = splitk
     d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    d.nbatch2, d.a_sb2, d.b_sb2, d.c_sb2 = nbatch2, a_sb2, b_sb2, c_sb2
     if splitk == 0 and Cm.is_cuda:
         ws = gemm_workspace(Cm.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -150,7 +151,7 @@ def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_
     if PROFILE is None:
         check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
         return
-    with _probe("gemm", 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch)):
+    with _probe("gemm", 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch) * max(1, nbatch2)):
         check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
 
 
