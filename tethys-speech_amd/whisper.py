@@ -563,7 +563,10 @@ class WhisperForConditionalGeneration(KernelBlocks):
             ops.gemm(logits, wl, acc, B * S, d, Vp, Vp, 1, 1, ldw, d, splitk=0)
             ops.cast_bf16(acc, d, dtmp, d, B * S, d)
         else:
-            ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d)
+            # (fp32 mode: the same split of the 51904-deep reduction, straight into the fp32 result)
+            self._guard_write(dtmp)
+            dtmp.zero_()
+            ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d, splitk=0)
         if early_update is not None:
             # lm_head: gradient final (weight gradient above, same stream), weights read for the last time by the dgrad just
             # enqueued on the main stream (the event _run_on_side records here orders the update behind it)
