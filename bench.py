@@ -2,7 +2,8 @@
 """Headline benchmark: audio-seconds/sec/node of the Whisper small-ref training step.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; the plain command
+   with N > 1 and no WORLD_SIZE starts exactly that as a child process and relays rank 0's line: self_launch)
 
 A step = forward + backward + gradient all-reduce (SUM, N > 1) + Adam + bf16 shadow
 refresh on one synthetic batch already resident in HBM (BASELINE.json configs[1]: Whisper
@@ -389,6 +390,42 @@ def throughput(clip_seconds, per_gpu_batch, world, steps, dt):
     return clip_seconds * per_gpu_batch * world * steps / dt
 
 
+def self_launch(gpus, script=None, argv=None):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves.
+
+    This process has made no GPU call (torch is not even imported yet), so it may start children; it never exec()s.  The
+    ranks are `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` in a CHILD process: their stderr
+    is inherited (progress lines stream through), their stdout is relayed line by line and rank 0's JSON line is printed
+    again as this process's LAST stdout line; the return code is the child's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback (the container hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script or os.path.abspath(__file__)]
+    cmd += sys.argv[1:] if argv is None else list(argv)
+    log(f"--gpus {gpus} without WORLD_SIZE: starting the ranks as a child process: {' '.join(cmd)}")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in child.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out  # held back: it must be the last line of OUR stdout
+        else:
+            print(out, flush=True)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        log("the ranks exited 0 without a JSON line")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -412,6 +449,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of timed CPU work for the first thread setting")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     if args.dropout is None:
         args.dropout = "reference" if args.precision == "bf16" else "off"
 

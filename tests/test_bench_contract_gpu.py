@@ -43,3 +43,22 @@ def test_bench_line_wav2vec2_contract(dev):
     assert KEYS <= set(d) and "roofline" in d and "roofline_classes" in d
     assert "Wav2Vec2-base" in d["metric"] and d["roofline"]["bound"] == "mfma"
     assert abs(d["value"] - 2.0 * 8 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_plain_command_self_launches_two_ranks(dev):
+    """`python3 bench.py --gpus 2` with no WORLD_SIZE in the environment starts its own ranks (child
+    process, torch.distributed.run) instead of exiting.  Rehearsed on the one card of this box: gloo as the exchange
+    backend, both ranks on device 0.  The line must be a valid N = 2 line with the exchange diagnostics."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TETHYS_DIST_BACKEND="gloo", TETHYS_ONE_DEVICE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-roofline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    d = json.loads(lines[-1])
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 30.0 * 16 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
+    c = d["config"]
+    assert c["rccl_ranks"] == 2 and c["exposed_exchange_ms"] is not None and len(c["host_enqueue_ms"]) == 2
+    assert "cpu_baseline" not in d  # rank 0 at N = 1 only

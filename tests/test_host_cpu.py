@@ -2,6 +2,7 @@
 (arena layout, strategy buckets, TF_CONFIG parsing, dataset batching), and the N>1
 gradient all-reduce path with world_size-2 gloo."""
 import ctypes
+import json
 import os
 import re
 import socket
@@ -421,3 +422,34 @@ def test_bench_pool_gives_every_rank_its_full_batch(world):
         assert len({tuple(x.tolist()) for x in flat}) == 8 * world  # distinct clips on every rank
         assert all(next(it).shape[0] == 8 for it in w2v)
 
+
+
+def test_bench_self_launch_relays_rank0_line(tmp_path, capfd):
+    """`python bench.py --gpus N` with no WORLD_SIZE must not lose the run.  bench.self_launch starts
+    `python -m torch.distributed.run --nproc-per-node N <script> <argv>` as a CHILD process (never exec), relays its stdout
+    and prints rank 0's JSON line as the last stdout line; the return code is the child's.  Here the ranks are a stand-in
+    script (the bench's own ranks need a GPU: tests/test_bench_contract_gpu.py runs the real thing with gloo on one
+    card): two gloo ranks all-reduce their rank + 1 and rank 0 prints the line."""
+    import bench
+    script = tmp_path / "ranks.py"
+    script.write_text(
+        "import json, os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)]); dist.all_reduce(t)\n"
+        "print('noise from rank', dist.get_rank(), flush=True)\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'metric': 'm', 'value': t.item(), 'n_gpus': int(os.environ['WORLD_SIZE']), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(int(os.environ.get('RANKS_RC', '0')))\n")
+    rc = bench.self_launch(2, script=str(script), argv=["--gpus", "2", "--steps", "3"])
+    out = [l for l in capfd.readouterr().out.splitlines() if l.strip()]
+    assert rc == 0
+    d = json.loads(out[-1])  # the JSON line is the LAST line whatever the ranks printed after it
+    assert d == {"metric": "m", "value": 3.0, "n_gpus": 2, "argv": ["--gpus", "2", "--steps", "3"]}
+    assert sum(l.startswith("noise from rank") for l in out) == 2
+    os.environ["RANKS_RC"] = "3"
+    try:
+        assert bench.self_launch(2, script=str(script), argv=[]) != 0  # a failing rank fails the launcher
+    finally:
+        del os.environ["RANKS_RC"]
+    capfd.readouterr()

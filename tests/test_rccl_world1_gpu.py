@@ -51,7 +51,9 @@ def _worker(port, q):
         torch.cuda.set_device(0)
         dev = "cuda:0"
 
-        def run(strat, precision, adam_under_backward=False):
+        ran = {}
+
+        def run(strat, precision, adam_under_backward=False, pipelined=False, tag=None):
             model = whisper.create_whisper_model("small", device=dev, precision=precision, seed=11, **KW)
             assert model._side is not None, "the overlapped step (weight-gradient stream) is what this test is about"
             strat.broadcast_parameters(model.arena.p)
@@ -59,10 +61,16 @@ def _worker(port, q):
             opt = optim.Adam(1e-3)
             keep, train.ADAM_UNDER_BACKWARD = train.ADAM_UNDER_BACKWARD, adam_under_backward
             try:
-                losses = [float(train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)),
-                                                             opt).item()) for f, l in _batches()]
+                losses = []
+                for f, l in _batches():
+                    losses.append(train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)),
+                                                               opt, pipelined=pipelined))
+                    if tag is not None:
+                        ran.setdefault(tag, []).append((getattr(opt, "early_buckets_ran", 0), bool(model._late_ev)))
+                losses = [float(x.item()) for x in losses]
             finally:
                 train.ADAM_UNDER_BACKWARD = keep
+            model.finish_late()
             torch.cuda.synchronize()
             return losses, model.arena.p.cpu().numpy(), model.arena.m.cpu().numpy()
 
@@ -87,6 +95,17 @@ def _worker(port, q):
         # Adam slice by slice under backward (on_bucket): the optimizer stream waits for each bucket's works
         strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=256 * 1024, force_collectives=True)
         out[("under_backward", "fp32")] = run(strat, "fp32", adam_under_backward=True)
+        # the early Adam slices WITH replicas (optim.Adam.begin_early_buckets: the LM-head and embedding
+        # buckets updated on the optimizer stream as soon as their own collective is done) and the late slice behind the
+        # exchange, in the pipelined step the training loops and the bench run
+        for precision in ("fp32", "bf16"):
+            strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=64 * 1024, force_collectives=True)
+            out[("early_buckets", precision)] = run(strat, precision, pipelined=True, tag=("early_buckets", precision))
+        # the bench's "same ranks without the exchange" run must keep that schedule
+        strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=64 * 1024, force_collectives=True)
+        strat.exchange_off = True
+        out[("early_buckets_off", "fp32")] = run(strat, "fp32", pipelined=True, tag=("early_buckets_off", "fp32"))
+        out["ran"] = ran
         torch.distributed.destroy_process_group()
         q.put(("ok", out))
     except BaseException as e:  # report instead of hanging the parent on q.get
@@ -135,3 +154,8 @@ def test_rccl_one_rank_exchange_is_the_identity(dev):
                 den = np.abs(m0).max()
                 assert np.abs(m1 - m0).max() <= 1e-2 * den, (ex, dt, precision, np.abs(m1 - m0).max(), den)
     close(out[("under_backward", "fp32")], out[("plain", "fp32")], "Adam under backward")
+    for key in (("early_buckets", "fp32"), ("early_buckets", "bf16"), ("early_buckets_off", "fp32")):
+        close(out[key], out[("plain", key[1])], key)
+        per_step = out["ran"][key]
+        # both slices (LM head, embedding table) ran early in every step, and the late slice was left running behind the step
+        assert all(n == 2 for n, _ in per_step) and all(late for _, late in per_step), (key, per_step)

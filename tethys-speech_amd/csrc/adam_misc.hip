@@ -679,7 +679,7 @@ extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, cons
 extern "C" int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
                            int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0 || (cols & 1) || cols > TMI_DROP_MAX_COLS || ld_in < cols || ld_out < cols || (resid && ld_res < cols) ||
-      !(p >= 0.f && p < 1.f)) {
+      !(p >= 0.f && tmi_drop_ok(p))) {
     tmi_set_error("tmi_dropout: bad argument (cols must be even, 0 <= p < 1)");
     return TMI_ERR_INVALID;
   }

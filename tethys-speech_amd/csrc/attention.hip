@@ -710,7 +710,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
               // registers 0..7: the even lane's hash (quad_perm [0,0,2,2]); 8..15: the odd lane's ([1,1,3,3]).  The swap is
               // the DPP operand of the AND that cuts this lane's 16 bits out of the 32 (low half for the even key, high
               // half - left in place, compared with the threshold shifted likewise - for the odd one): one instruction
-              // instead of move + bit-field extract.  (s_nop: a DPP read needs two wait states after the VALU write of
+              // instead of move + bit-field extract.  REQUIRES a full EXEC mask: a DPP read from an inactive lane returns
+              // stale data (bound_ctrl is off), and all four lanes of a quad are active here only because nothing above
+              // this `!edge` body exits lane-divergently - keep it that way.  (s_nop: a DPP read needs two wait states after the VALU write of
               // its source, and the hazard recogniser does not look inside asm.)
               uint32_t cut;
               if (e < 8)
@@ -806,7 +808,7 @@ int pick_ksplit(const tmi_attn_desc& d) {
 
 int check_common(const tmi_attn_desc& d) {
   if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
-      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && d.dropout_p < 1.f) ||
+      (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && tmi_drop_ok(d.dropout_p)) ||
       (d.dropout_p > 0.f && d.Tk > TMI_DROP_MAX_COLS))
     return 0;
   return ok_mat(d.q, d.q_sb, d.q_st) && ok_mat(d.k, d.k_sb, d.k_st) && ok_mat(d.v, d.v_sb, d.v_st) &&

@@ -289,7 +289,7 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
       return TMI_ERR_INVALID;
     }
   }
-  if (!(d.dropout_p >= 0.f && d.dropout_p < 1.f) || (d.dropout_p > 0.f && (d.nbatch != 1 || d.splitk != 1 || (d.N & 1) || d.N > TMI_DROP_MAX_COLS))) {
+  if (!(d.dropout_p >= 0.f && tmi_drop_ok(d.dropout_p)) || (d.dropout_p > 0.f && (d.nbatch != 1 || d.splitk != 1 || (d.N & 1) || d.N > TMI_DROP_MAX_COLS))) {
     tmi_set_error("tmi_gemm: epilogue dropout needs 0 <= p < 1, nbatch == 1, splitk == 1 and an even N <= 2^17");
     return TMI_ERR_INVALID;
   }

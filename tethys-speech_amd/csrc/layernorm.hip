@@ -428,7 +428,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
       C % vec || !al16(x) || !al16(dy) || !al16(dx) || (masked && (!colsum || !al16(masked) || (C & 1))) ||
-      !(dropout_p >= 0.f && dropout_p < 1.f)) {
+      !(dropout_p >= 0.f && tmi_drop_ok(dropout_p))) {
     tmi_set_error("tmi_layernorm_bwd: bad argument");
     return TMI_ERR_INVALID;
   }

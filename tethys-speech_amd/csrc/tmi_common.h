@@ -107,6 +107,9 @@ __host__ __device__ __forceinline__ uint32_t tmi_pair_hash(tmi_rowkey rk, uint32
   return tmi_mul24(h, 0x85EBCBu);
 }
 __host__ __device__ __forceinline__ uint32_t tmi_drop_thr(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+// rates the 16-bit threshold can express: thr <= 65535 (p < ~0.999992).  thr == 65536 would make the keep scale infinite and
+// overflow the in-place form `thr << 16` of the dK/dV kernel (its odd keys would all be kept while fwd / dQ drop them)
+__host__ __device__ __forceinline__ bool tmi_drop_ok(float p) { return p < 1.f && tmi_drop_thr(p) <= 65535u; }
 __host__ __device__ __forceinline__ float tmi_keep_scale(uint32_t thr) { return 65536.0f / (float)(65536u - thr); }
 // key of a stream: seed (64 bit) and a 32-bit stream id (batch*heads + head for attention; 0 for flat tensors)
 __host__ __device__ __forceinline__ uint32_t tmi_stream_key(uint64_t seed, uint32_t stream_id) {

@@ -93,6 +93,9 @@ class Adam:
         arithmetic is unchanged (Adam is elementwise): the result is bit for bit the single-launch update."""
         self.iterations += 1
         self._early = []
+        if self.row_sparse and self.weight_decay == 0.0 and hasattr(model, "embedding_tables"):
+            for off, rows, _ in model.embedding_tables():   # created (and filled) HERE, on the main stream, before any
+                self._row_flags(model, off, rows)            # side-stream work of this step is ordered behind it
         blocks = self.EARLY_BLOCKS  # a throttled grid: the full-width kernel saturates HBM and starves the chain it runs under
 
         def update(lo, hi):
@@ -101,6 +104,69 @@ class Adam:
         return update
 
     EARLY_BLOCKS = int(os.environ.get("TMI_ADAM_EARLY_BLOCKS", "256"))
+
+    # -- early slices with replicas: the same two slices, released by the bucket that carries them ---------------
+    def begin_early_buckets(self, model, strategy, ranges, grad_scale=1.0):
+        """``begin_early`` when the gradients are exchanged first (replicas, W:834): the strategy hands every finished bucket to
+        ``_early_bucket``; a bucket that carries one of ``ranges`` whole (Whisper: the LM head, the embedding table - the two
+        160 MB variables, each the bulk of its bucket) is updated on the optimizer stream as soon as ITS collective is done,
+        on the throttled grid, while backward goes on; every other bucket stays with the strategy and is updated by
+        ``apply_gradients`` at the end of the step, as without this.  ``early_buckets_ran`` counts the slices of the last step."""
+        self.iterations += 1
+        self._early = []
+        self.early_buckets_ran = 0
+        if self.row_sparse and self.weight_decay == 0.0 and hasattr(model, "embedding_tables"):
+            for off, rows, _ in model.embedding_tables():
+                self._row_flags(model, off, rows)
+        if model.device.type == "cuda" and getattr(self, "_os", None) is None:
+            self._os = torch.cuda.Stream(device=model.device)
+        self._eb = (model, strategy, list(ranges), grad_scale)
+        strategy.on_bucket = self._early_bucket
+
+    def _early_bucket(self, lo, hi, works, post):
+        model, strategy, ranges, grad_scale = self._eb
+        if not any(lo <= r_lo and r_hi <= hi for r_lo, r_hi in ranges):
+            strategy._works.extend(works)   # not ours: the strategy waits for it in all_reduce_gradients
+            if post is not None:
+                strategy._post.append(post)
+            return
+        if model.device.type != "cuda":     # (host tensors, the gloo tests: no streams, works already complete)
+            for w in works:
+                w.wait()
+            if post is not None:
+                post()
+            self._update(model, lo, hi, grad_scale, True, 0)
+        else:
+            self._os.wait_stream(torch.cuda.current_stream(model.device))  # last readers of these weights in this step
+            for st in model.gradient_streams():
+                self._os.wait_stream(st)
+            prev = ops.set_stream(self._os.cuda_stream)
+            try:
+                with torch.cuda.stream(self._os):
+                    for w in works:         # the optimizer stream (not the host) waits for the bucket's collective
+                        w.wait()
+                    if post is not None:
+                        post()
+                    self._update(model, lo, hi, grad_scale, True, self.EARLY_BLOCKS)
+            finally:
+                ops.set_stream(prev)
+        self._early.append((lo, hi))
+        self.early_buckets_ran += 1
+
+    def finish_early_buckets(self, model, strategy):
+        """After ``apply_gradients``: give the bucket hook back and order the compute stream after the optimizer stream."""
+        strategy.on_bucket = None
+        self._eb = None
+        if model.device.type == "cuda":
+            torch.cuda.current_stream(model.device).wait_stream(self._os)
+
+    def abort_early(self):
+        """The step that called ``begin_early`` raised before ``apply_gradients``: forget its slices and give the step count
+        back, so the next step is a whole one (slices that already ran have moved their parameters: the caller's model is
+        as undefined as after any half-finished step, but the optimizer's bookkeeping is consistent again)."""
+        if self.__dict__.get("_early") is not None:
+            self._early = None
+            self.iterations -= 1
 
     def _update(self, model, lo, hi, grad_scale, zero_grad, max_blocks):
         """Adam over arena range [lo, hi).  The parts of it that are embedding tables (``model.embedding_tables()``:
@@ -146,6 +212,16 @@ class Adam:
         if f is None:
             fresh = self.iterations <= 1 and not a.__dict__.get("adam_state_dirty", False)
             f = store[off] = (torch.zeros if fresh else torch.ones)(rows, dtype=torch.uint8, device=model.device)
+            # The fill above is enqueued on torch's CURRENT stream; tmi_adam_step_rows reads and writes the flags on the
+            # stream ``ops`` is pinned to (the second stream, for an early / late slice).  Nothing else orders the two, so
+            # the consumer stream waits for the fill here (a fill landing after the kernel re-marks touched rows
+            # idle, and they are skipped for good).
+            if model.device.type == "cuda":
+                cur = torch.cuda.current_stream(model.device)
+                if ops.stream() != cur.cuda_stream:
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    torch.cuda.ExternalStream(ops.stream(), device=model.device).wait_event(ev)
         return f
 
     @staticmethod

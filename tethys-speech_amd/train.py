@@ -19,14 +19,15 @@ from .whisper import create_whisper_model
 # the Adam kernel instead of a separate fill pass.
 ADAM_UNDER_BACKWARD = os.environ.get("TMI_ADAM_UNDER_BACKWARD", "0") != "0"
 # What does pay (round 3): only the slices whose gradients are final while the chip is idle anyway - the LM head and the
-# embedding table under the decoder's backward chain (optim.Adam.begin_early).  One replica only: with replicas the
-# gradients have to be exchanged first.  TMI_ADAM_EARLY=0 restores the single update at the end of the step.
+# embedding table under the decoder's backward chain (optim.Adam.begin_early).  With replicas the gradients have to be
+# exchanged first: the same two slices run as soon as the bucket that carries them has been summed
+# (optim.Adam.begin_early_buckets).  TMI_ADAM_EARLY=0 restores the single update at the end of the step.
 ADAM_EARLY = os.environ.get("TMI_ADAM_EARLY", "1") != "0"
 
 
 # The decoder layers' share of the update (26 % of small-ref) on the second stream UNDER THE NEXT STEP's encoder forward
 # (optim.Adam.apply_gradients(late=...)).  Only for callers that say the next thing they do is another step
-# (``pipelined=True``: the training loops and the bench), one replica; TMI_ADAM_LATE=0 switches it off.
+# (``pipelined=True``: the training loops and the bench); TMI_ADAM_LATE=0 switches it off.
 ADAM_LATE = os.environ.get("TMI_ADAM_LATE", "1") != "0"
 
 
@@ -46,23 +47,40 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer, pipelined=Fa
     overlapped = ADAM_UNDER_BACKWARD and model.device.type == "cuda"
     if overlapped:  # Adam slice by slice as buckets become final (and reduced), under the rest of backward
         optimizer.begin_overlapped(model, strategy)
-    early = None
-    if (ADAM_EARLY and not overlapped and not strategy._collective and model.device.type == "cuda" and features.shape[0] > 0
-            and model._side is not None):
+    # the early / late Adam slices: one schedule for every run of the same job.  Whether there are replicas is a property
+    # of the job (world, force_collectives), NOT of ``exchange_off`` - bench.py's "step without the exchange" must be the
+    # same schedule minus the collectives
+    replicas = strategy.world > 1 or strategy.force_collectives
+    can_early = (ADAM_EARLY and not overlapped and model.device.type == "cuda" and features.shape[0] > 0
+                 and model._side is not None)
+    early, early_buckets = None, False
+    if can_early and not replicas:
         early = optimizer.begin_early(model)
-    if features.shape[0] > 0:
-        loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready, early_update=early)
-    else:
-        # same reports as a real backward, so this rank's bucket launches match its peers' one for one
-        model.report_zero_gradients(strategy.gradients_ready)
-        loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+    elif can_early and hasattr(model, "early_adam_ranges"):
+        # replicas: the same two slices, each as soon as the bucket that carries it has been summed (optim.begin_early_buckets)
+        optimizer.begin_early_buckets(model, strategy, model.early_adam_ranges())
+        early_buckets = True
+    try:
+        if features.shape[0] > 0:
+            loss = model.forward_backward(features, labels, grad_ready=strategy.gradients_ready, early_update=early)
+        else:
+            # same reports as a real backward, so this rank's bucket launches match its peers' one for one
+            model.report_zero_gradients(strategy.gradients_ready)
+            loss = torch.zeros(1, dtype=torch.float32, device=model.device)
+    except BaseException:
+        optimizer.abort_early()   # (a stale slice list would make the next apply_gradients skip those ranges)
+        if early_buckets:
+            strategy.on_bucket = None
+        raise
     if overlapped:
         optimizer.finish_overlapped(model, strategy)
     else:
         late = None
-        if pipelined and ADAM_LATE and early is not None and hasattr(model, "late_adam_range"):
+        if pipelined and ADAM_LATE and (early is not None or early_buckets) and hasattr(model, "late_adam_range"):
             late = model.late_adam_range()
         optimizer.apply_gradients(model, strategy, zero_grad=True, late=late)
+        if early_buckets:
+            optimizer.finish_early_buckets(model, strategy)
     return strategy.reduce_sum(loss.clone())
 
 
@@ -328,7 +346,7 @@ def load_checkpoint(model, optimizer, path, dataset=None):
 # ---------------------------------------------------------------------------------------
 # Wav2Vec2 (speech_jobs/wav2vec2_dist.py, "V:")
 # ---------------------------------------------------------------------------------------
-def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer, pipelined=False):
+def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer, pipelined=False, forced_codes=None):
     """V:1186-1260.  Per replica: forward, loss / num_replicas, backward, LOCAL
     clip_by_global_norm(1.0) (V:1243, before the exchange), gradient all-reduce SUM (=> mean),
     Keras clipnorm(1.0) per variable (V:1274, after aggregation), Adam; returns
@@ -336,7 +354,7 @@ def wav2vec2_train_step(strategy, model, audio, neg_indices, optimizer, pipeline
     from . import ops
     a = model.arena
     if audio.shape[0] > 0:
-        loss = model.forward_backward(audio, neg_indices, num_replicas=strategy.num_replicas_in_sync)
+        loss = model.forward_backward(audio, neg_indices, num_replicas=strategy.num_replicas_in_sync, forced_codes=forced_codes)
     else:  # the reference's empty-batch branch (V:1196-1198, V:1250-1254)
         model.finish_late()
         a.g.zero_()

@@ -328,17 +328,18 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self._buf("clip_vars", (self.n_var,), f32)
 
     # -- forward + backward ----------------------------------------------------------------
-    def forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
+    def forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1, forced_codes=None):
         """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
-        ``_forward_backward``."""
+        ``_forward_backward``.  ``forced_codes`` (int32 [B, T, G], parity runs only): the quantiser takes these code
+        choices instead of its own argmin (tmi_vq_assign) - an argument of THIS call, never state of the model."""
         self.begin_step()
         try:
-            return self._forward_backward(audio, neg_indices, num_replicas)
+            return self._forward_backward(audio, neg_indices, num_replicas, forced_codes)
         finally:
             self.end_step()
             self._drop_step += 1
 
-    def _forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1):
+    def _forward_backward(self, audio: torch.Tensor, neg_indices: torch.Tensor, num_replicas: int = 1, forced=None):
         """One replica's V:1199-1240: returns the device scalar ``scaled_loss`` =
         (contrastive + 0.1 * (-perplexity)) / num_replicas; gradients of it land in ``arena.g``."""
         cfg = self.config
@@ -413,7 +414,6 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         Gq, Nc = cfg.num_codevector_groups, cfg.num_codevectors_per_group
         gd = cfg.codevector_dim // Gq
         self._dense_fwd(hproj, "quantizer.projection.kernel", ws["qin"])
-        forced = self.__dict__.get("forced_codes")
         if forced is not None:  # teacher-forced run: int32 [B*T, G] codes replace the argmin (tmi_vq_assign)
             ws["code_idx"].copy_(forced.reshape(ws["code_idx"].shape))
             ops.vq_assign(a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R, Gq, Nc, gd)

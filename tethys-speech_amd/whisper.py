@@ -375,6 +375,13 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # measured too: from layer 1 the chain waits for it, +0.3 ms; from layer 2 it is level, 8.30 vs 8.32 ms - not kept)
         return [(a.offsets["decoder.cross_kv.kernel"], a.offsets["lm_head.kernel"], "dec")]
 
+    def early_adam_ranges(self):
+        """The two variables whose gradients are final while the decoder's backward still runs (the EARLY slices):
+        the LM head (last in the arena) and the decoder's embedding table."""
+        a = self.arena
+        e_lo = a.offsets["decoder.embed_tokens.embeddings"]
+        return [(a.offsets["lm_head.kernel"], a.numel), (e_lo, e_lo + a.grad("decoder.embed_tokens.embeddings").numel())]
+
     def forward_backward(self, features: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
                          grad_ready=None, early_update=None):
         """Pins the launch stream for the duration of the step (KernelBlocks.begin_step), then runs
