@@ -438,7 +438,7 @@ def test_wav2vec2_base_loss_curve_golden(dev, precision, tol):
         print(f"wav2vec2-base B=2 bf16 FREE-RUNNING steps 0-1: rel {['%.1e' % r for r in frel]}")
         assert all(np.isfinite(free)), free
         from _margins import within as _w
-        _w("wav2vec2-base B=2 bf16 free-running steps 0-1 max rel", max(frel), 5e-2, (free, gold["losses"][:2]))
+        _w("wav2vec2-base B=2 bf16 free-running steps 0-1 max rel", max(frel), 2e-2, (free, gold["losses"][:2]))
     rel = [abs(x - y) / max(1.0, abs(y)) for x, y in zip(got, gold["losses"])]
     print(f"wav2vec2-base B=2 golden {precision}: rel per step {['%.1e' % r for r in rel]}")
     from _margins import within

@@ -57,7 +57,24 @@ struct FastParams {
   uint32_t drop_thr, drop_key;  // epilogue dropout (desc.dropout_p): threshold (0 = off) and stream key
   float drop_scale;
   int64_t split_c_stride;  // != 0: split s stores (no atomics) to C + s * split_c_stride (workspace slabs)
+  int slots;               // persistent eight-phase kernel: tile slots (8 * ptm * ptn, padding included) dealt over gridDim.x workgroups
+  int epi;                 // epilogue class of the lean interior path (EPI_*, epi_class()); 0 = the generic code only
 };
+
+// What an interior 32x64 piece has to do besides bias (+ q scale), decided once per launch on the host.  The generic
+// epilogue tests every feature of tmi_gemm_desc per pass with all of its pointers live (it measured ~800 instructions
+// and ~4.8 k cycles per piece with two waves per SIMD, whatever the features in use); a class is straight-line code.
+constexpr int EPI_GENERIC = 0, EPI_SIMPLE = 1 /* bias, scale, GELU + saved pre-activation */, EPI_AUXIN = 2 /* x GELU'(aux_in) */,
+              EPI_RESID = 3 /* bias, dropout, + residual */, EPI_ACC = 4 /* C += */;
+inline int epi_class(const tmi_gemm_desc& d, bool wide) {
+  static const int off = [] { const char* e = getenv("TMI_GEMM_LEAN_EPI"); return e && atoi(e) == 0; }();
+  if (off || !wide || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15 || d.bias_sb % 4))) return EPI_GENERIC;
+  const bool drop = d.dropout_p > 0.f;
+  if (d.accumulate) return (!d.aux_in && !d.resid && !d.act && !d.aux_out && !drop && d.scale_cols <= 0) ? EPI_ACC : EPI_GENERIC;
+  if (d.aux_in) return (!d.resid && !d.act && !d.aux_out && !drop && d.scale_cols <= 0) ? EPI_AUXIN : EPI_GENERIC;
+  if (d.resid) return (!d.act && !d.aux_out && d.scale_cols <= 0) ? EPI_RESID : EPI_GENERIC;
+  return drop ? EPI_GENERIC : EPI_SIMPLE;
+}
 
 // bijective XCD-aware remap: consecutive new ids share an XCD
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -161,6 +178,9 @@ __device__ __forceinline__ bf16x8 frag_ks(const char* tile, int col_base, int kk
   return __builtin_shufflevector(part[0], part[1], 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// NI == 2 (the wave's output goes through wide_epilogue): the MFMA operands are passed SWAPPED, so an accumulator holds the
+// block of C^T - lane = row (lane & 31), register r = column 8 (r >> 2) + 4 (lane >> 5) + (r & 3): four consecutive
+// columns per register quad, which is what lets the epilogue stage it with 16-byte LDS writes.
 template <bool A_KS, bool B_KS, int MI, int NI, bool A64 = false, bool B64 = false>
 __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int row_base, int col_base, int lane,
                                          f32x16 (&acc)[MI][NI]) {
@@ -182,13 +202,23 @@ __device__ __forceinline__ void mma_tile(const char* As, const char* Bs, int row
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = NI == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ni], a[mi], acc[mi][ni], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
   }
 }
 
 // ---- wide epilogue helpers
 template <typename TC> struct Vec8;
 template <> struct Vec8<float> {
+  typedef float raw_t __attribute__((ext_vector_type(8)));
+  static __device__ __forceinline__ raw_t load_raw(const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  static __device__ __forceinline__ void widen(const raw_t& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = r[i];
+  }
   static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -200,6 +230,12 @@ template <> struct Vec8<float> {
   }
 };
 template <> struct Vec8<bf16_t> {
+  typedef bf16x8 raw_t;
+  static __device__ __forceinline__ raw_t load_raw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void widen(const raw_t& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+  }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -213,22 +249,130 @@ template <> struct Vec8<bf16_t> {
   }
 };
 
-__device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((col * 4) ^ ((row & 1) << 4)); }
+__device__ unsigned long long g_gemm_stamps[8];  // diagnostics (ABL == 8): cycles per loop phase, block 0 wave 0
 
-// One 32x64 piece of a wave's output (accumulator blocks a0 | a1) whose top-left element is
-// C[mw][nw]; E is the wave's private 8 KiB staging image.
-template <typename TC>
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ unsigned long long g_epi_stamps[8];   // diagnostics (TMI_GEMM_DBG & 32): inside wide_epilogue, block 8 wave 0, first piece
+
+// Staging image of one 32x64 fp32 piece: 32 rows of 256 B; the 16-byte chunk c (four columns) of row r lives at
+// r * 256 + ((c ^ (r & 7)) << 4).  Conflict-free both ways: the accumulator layout writes one chunk per lane with eight
+// consecutive rows per ds_write_b128 lane group (the XOR spreads them over the 32 banks), the row-major read-back
+// (8 lanes x 2 chunks per row, 8 rows per instruction) hits every bank group of ds_read_b128 once.
+__device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((((col >> 2) ^ (row & 7)) << 4) | ((col & 3) << 2)); }
+
+// The lean interior path: the piece lies wholly inside C and the launch is of class CLS.  Four passes of 8 rows; a lane
+// owns 8 consecutive columns of one row per pass (16-byte accesses throughout).
+template <typename TC, int CLS, int AHEAD>
+__device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, int64_t mw, int64_t nw, int64_t bz, int lane) {
+  const tmi_gemm_desc& d = P.d;
+  typedef typename Vec8<TC>::raw_t raw_t;
+  const int chunk = lane & 7, rsub = lane >> 3;
+  const int64_t n = nw + chunk * 8;
+  const int64_t off0 = (mw + rsub) * d.ldc + n, step = 8 * d.ldc;
+  TC* cp = reinterpret_cast<TC*>(d.C) + bz * d.c_sb + (int64_t)blockIdx.y * P.split_c_stride + off0;
+  const char* Elo = E + rsub * 256 + (((2 * chunk) ^ rsub) << 4);
+  const char* Ehi = E + rsub * 256 + (((2 * chunk + 1) ^ rsub) << 4);
+  float bv[8];
+  if (d.bias) {  // (16-byte aligned: epi_class)
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + bz * d.bias_sb + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + bz * d.bias_sb + n + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bv[i] = b0[i]; bv[4 + i] = b1[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+  }
+  float sv[8];
+  const bool scaled = CLS == EPI_SIMPLE && nw < d.scale_cols;  // (uniform: the wave's 64 columns against scale_cols)
+  if (scaled) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sv[i] = (n + i < d.scale_cols) ? d.scale : 1.f;
+  }
+  const TC* xp = nullptr;  // the class's extra operand, walked like cp
+  int64_t xstep = step;
+  if constexpr (CLS == EPI_AUXIN) xp = reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb + off0;
+  if constexpr (CLS == EPI_RESID) { xp = reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb + (mw + rsub) * d.r_ld + n; xstep = 8 * d.r_ld; }
+  if constexpr (CLS == EPI_ACC) xp = cp;
+  TC* ap = (CLS == EPI_SIMPLE && d.aux_out) ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb + off0 : nullptr;
+#pragma unroll
+  for (int pp = 0; pp < 4; pp += AHEAD) {
+    raw_t x[AHEAD];
+    f32x4 lo[AHEAD], hi[AHEAD];
+    if constexpr (CLS != EPI_SIMPLE) {
+#pragma unroll
+      for (int j = 0; j < AHEAD; ++j) x[j] = Vec8<TC>::load_raw(xp + (pp + j) * xstep);
+    }
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+      lo[j] = *reinterpret_cast<const f32x4*>(Elo + (pp + j) * 2048);
+      hi[j] = *reinterpret_cast<const f32x4*>(Ehi + (pp + j) * 2048);
+    }
+#pragma unroll
+    for (int j = 0; j < AHEAD; ++j) {
+      float v[8], t[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { v[i] = lo[j][i] + bv[i]; v[4 + i] = hi[j][i] + bv[4 + i]; }
+      if constexpr (CLS == EPI_SIMPLE) {
+        if (scaled) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] *= sv[i];
+        }
+        if (ap) Vec8<TC>::store(ap + (pp + j) * step, v);
+        if (d.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
+        }
+      } else {
+        Vec8<TC>::widen(x[j], t);
+        if constexpr (CLS == EPI_AUXIN) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_t<TC>(t[i]);
+        } else {
+          if (CLS == EPI_RESID && P.drop_thr) tmi_drop8(v, mw + rsub + (pp + j) * 8, n, P.drop_key, P.drop_thr, P.drop_scale);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += t[i];
+        }
+      }
+      Vec8<TC>::store(cp + (pp + j) * step, v);
+    }
+  }
+}
+
+// One 32x64 piece of a wave's output (accumulator blocks a0 | a1, C^T layout: see mma_tile) whose top-left element is
+// C[mw][nw]; E is the wave's private 8 KiB staging image.  Round 4: 8 ds_write_b128 instead of 64 ds_write_b32 per piece
+// (the old form cost ~4 k cycles per piece with eight waves at it: LDS stores run at 64 B/clk/CU), and the row passes
+// taken AHEAD at a time, with their LDS reads and epilogue operand loads issued before the first use (AHEAD = 1 for the
+// kernels that have no registers to spare: 128 accumulator registers, or a 128-register budget).
+template <typename TC, int AHEAD = 2>
 __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16& a0, const f32x16& a1, char* E,
                                               int64_t mw, int64_t nw, int64_t bz, int lane, bool atomic) {
   const tmi_gemm_desc& d = P.d;
+  const bool st = (P.dbg & 32) && blockIdx.x == 8 && threadIdx.x < 64;
+  unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+  if (st) e0 = stamp();
   {
-    const int c = lane & 31, h = lane >> 5;
+    const int m = lane & 31, h = lane >> 5, sw = m & 7;
+    char* Er = E + m * 256;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      *reinterpret_cast<float*>(E + epi_off(row, c)) = a0[reg];
-      *reinterpret_cast<float*>(E + epi_off(row, 32 + c)) = a1[reg];
+    for (int q = 0; q < 4; ++q) {
+      *reinterpret_cast<f32x4*>(Er + (((2 * q + h) ^ sw) << 4)) = f32x4{a0[4 * q], a0[4 * q + 1], a0[4 * q + 2], a0[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(Er + (((8 + 2 * q + h) ^ sw) << 4)) = f32x4{a1[4 * q], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
     }
+  }
+  if (st) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); e1 = stamp(); }
+  if (P.epi != EPI_GENERIC && !atomic && mw + 32 <= d.M && nw + 64 <= d.N && !(P.dbg & 8)) {  // (uniform over the wave)
+    if (P.epi == EPI_SIMPLE) lean_rows<TC, EPI_SIMPLE, AHEAD>(P, E, mw, nw, bz, lane);
+    else if (P.epi == EPI_AUXIN) lean_rows<TC, EPI_AUXIN, AHEAD>(P, E, mw, nw, bz, lane);
+    else if (P.epi == EPI_RESID) lean_rows<TC, EPI_RESID, AHEAD>(P, E, mw, nw, bz, lane);
+    else lean_rows<TC, EPI_ACC, AHEAD>(P, E, mw, nw, bz, lane);
+    if (st) {
+      e3 = stamp();
+      if (lane == 0 && g_epi_stamps[7] == 0) { g_epi_stamps[0] = e1 - e0; g_epi_stamps[1] = 0; g_epi_stamps[2] = e3 - e1; g_epi_stamps[7] = 1; }
+    }
+    return;
   }
   TC* C = reinterpret_cast<TC*>(d.C) + bz * d.c_sb + (int64_t)blockIdx.y * P.split_c_stride;
   if (atomic && P.split_c_stride == 0) {  // split-K: fp32 atomics, 256 contiguous bytes per wave-instruction
@@ -247,39 +391,36 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
   TC* aux_out = d.aux_out ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb : nullptr;
   const TC* aux_in = d.aux_in ? reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb : nullptr;
   const TC* resid = d.resid ? reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb : nullptr;
-  const int chunk = lane & 7;
+  const int chunk = lane & 7, rsub = lane >> 3;
   const int64_t n = nw + chunk * 8;
   if (n >= d.N) return;
   const bool full = P.wide && (n + 8 <= d.N);
   float bv[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) bv[i] = (d.bias && n + i < d.N) ? d.bias[bz * d.bias_sb + n + i] : 0.f;
+  // this lane's two chunks of row 8 p + rsub: (row & 7) == rsub for every pass, so the passes differ by an immediate
+  const char* Elo = E + rsub * 256 + (((2 * chunk) ^ rsub) << 4);
+  const char* Ehi = E + rsub * 256 + (((2 * chunk + 1) ^ rsub) << 4);
+  if (st) e2 = stamp();
+  if (full) {  // (edge pieces and launches outside the lean classes: one pass at a time, every feature tested)
 #pragma unroll 1
-  for (int p = 0; p < 4; ++p) {
-    const int row = p * 8 + (lane >> 3);
-    const int64_t m = mw + row;
-    if (m >= d.M) continue;
-    float v[8];
-    {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(E + epi_off(row, chunk * 8));
-      const f32x4 b = *reinterpret_cast<const f32x4*>(E + epi_off(row, chunk * 8 + 4));
+    for (int p = 0; p < 4; ++p) {
+      const int64_t m = mw + p * 8 + rsub;
+      if (m >= d.M) continue;
+      const int64_t idx = m * d.ldc + n;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(Elo + p * 2048), hi = *reinterpret_cast<const f32x4*>(Ehi + p * 2048);
+      float v[8], t[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
-    }
-    const int64_t idx = m * d.ldc + n;
+      for (int i = 0; i < 4; ++i) { v[i] = lo[i] + bv[i]; v[4 + i] = hi[i] + bv[4 + i]; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] += bv[i];
-      if (n + i < d.scale_cols) v[i] *= d.scale;
-    }
-    if (full) {
-      float t[8];
+      for (int i = 0; i < 8; ++i)
+        if (n + i < d.scale_cols) v[i] *= d.scale;
       if (d.accumulate) {
         Vec8<TC>::load(C + idx, t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += t[i];
       }
-      if (aux_out) Vec8<TC>::store(aux_out + idx, v);
+      if (aux_out && !(P.dbg & 8)) Vec8<TC>::store(aux_out + idx, v);
       if (d.act == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
@@ -295,20 +436,40 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += t[i];
       }
+      if (P.dbg & 8) { asm volatile("" ::"v"(v[0]), "v"(v[3]), "v"(v[7])); continue; }  // diagnostics: everything but the store
       Vec8<TC>::store(C + idx, v);
-    } else {
+    }
+    if (st) {
+      e3 = stamp();
+      if (lane == 0 && g_epi_stamps[7] == 0) { g_epi_stamps[0] = e1 - e0; g_epi_stamps[1] = e2 - e1; g_epi_stamps[2] = e3 - e2; g_epi_stamps[7] = 1; }
+    }
+    return;
+  }
+  // ragged right edge / unaligned output: element by element
+#pragma unroll 1
+  for (int p = 0; p < 4; ++p) {
+    const int64_t m = mw + p * 8 + rsub;
+    if (m >= d.M) continue;
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Elo + p * 2048);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(Ehi + p * 2048);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (n + i >= d.N) break;
-        float x = v[i];
-        if (d.accumulate) x += to_f32(C[idx + i]);
-        if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
-        if (d.act == 1) x = gelu_fwd_t<TC>(x);
-        if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
-        if (P.drop_thr) x = tmi_drop1(x, m, n + i, P.drop_key, P.drop_thr, P.drop_scale);
-        if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
-        C[idx + i] = from_f32<TC>(x);
-      }
+      for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    const int64_t idx = m * d.ldc + n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (n + i >= d.N) break;
+      float x = v[i] + bv[i];
+      if (n + i < d.scale_cols) x *= d.scale;
+      if (d.accumulate) x += to_f32(C[idx + i]);
+      if (aux_out) aux_out[idx + i] = from_f32<TC>(x);
+      if (d.act == 1) x = gelu_fwd_t<TC>(x);
+      if (aux_in) x *= gelu_grad_t<TC>(to_f32(aux_in[idx + i]));
+      if (P.drop_thr) x = tmi_drop1(x, m, n + i, P.drop_key, P.drop_thr, P.drop_scale);
+      if (resid) x += to_f32(resid[m * d.r_ld + n + i]);
+      C[idx + i] = from_f32<TC>(x);
     }
   }
 }
@@ -400,13 +561,6 @@ __device__ __forceinline__ void wide_epilogue32(const FastParams& P, const f32x1
   }
 }
 
-__device__ unsigned long long g_gemm_stamps[8];  // diagnostics (ABL == 8): cycles per loop phase, block 0 wave 0
-
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -746,7 +900,7 @@ void gemm_fast_kernel(const FastParams P) {
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int p = 0; p < MI; ++p)
-    wide_epilogue<TC>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, atomic);
+    wide_epilogue<TC, (MI * NI * 16 <= 32 ? 2 : 1)>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, atomic);
   }
 }
 
@@ -802,21 +956,39 @@ __device__ __forceinline__ void p8_barrier() {
 // the Q11 / Q10 phases issue 4 MFMAs instead of 8, A^1 is an 8 KiB half-tile staged with ONE LDS-DMA per lane, so the
 // counted waits are vmcnt(7) / vmcnt(5)).  For outputs whose 256-row tiling leaves CUs idle or a round mostly empty
 // (M = 12000, N = 768: 141 tiles on 256 CUs -> 189 tiles of 3/4 the work).  k-contiguous A only.
-template <typename TC, bool A_KS, bool B_KS, int BM = 256>
+template <typename TC, bool A_KS, bool B_KS, int BM = 256, bool PERSIST = false, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   static_assert(BM == 256 || (BM == 192 && !A_KS), "192-row tiles: k-contiguous A only");
   constexpr int WR = BM / 2;          // rows per wave row
   constexpr int NMI = WR / 32;        // 32-row accumulator blocks per wave: 4 or 3
   constexpr int MI1 = NMI - 2;        // row blocks of the A^1 half: 2 or 1
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB] (+ 32 KiB of epilogue staging, PERSIST)
   const tmi_gemm_desc& d = P.d;
-  const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
-  int ltm, ltn;
-  if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
-  else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
-  const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
-  if (tm >= P.tiles_m || tn >= P.tiles_n) return;
-  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * 256;
+  // tile slot -> tile coordinates (XCD-aware, see gemm_fast_kernel); false for the padding slots of a ragged partition
+  auto decode = [&](int slot, int64_t& m0_, int64_t& n0_) -> bool {
+    const int xcd = slot & 7, lidx = slot >> 3;
+    int ltm, ltn;
+    if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
+    else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
+    const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
+    m0_ = (int64_t)tm * BM;
+    n0_ = (int64_t)tn * 256;
+    return tm < P.tiles_m && tn < P.tiles_n;
+  };
+  // PERSIST: workgroup b walks the slots b, b + gridDim.x, ... (gridDim.x % 8 == 0: it stays on its XCD and the workgroups
+  // of an XCD that are resident together work on consecutive slots of its rectangle, i.e. share operand panels in L2)
+  auto next_slot = [&](int slot, int64_t& m0_, int64_t& n0_) -> int {
+    while (slot < P.slots && !decode(slot, m0_, n0_)) slot += (int)gridDim.x;
+    return slot;
+  };
+  int64_t m0, n0;
+  int slot = blockIdx.x;
+  if constexpr (PERSIST) {
+    slot = next_slot(slot, m0, n0);
+    if (slot >= P.slots) return;
+  } else {
+    if (!decode(slot, m0, n0)) return;
+  }
   const int64_t bz = blockIdx.z;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -841,6 +1013,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   //   row/column groups laid along the image columns.
   unsigned offA[2][2], offB[2][2];
   int krs[2];  // k-row of this lane's two loads (k-strided images)
+  auto set_offsets = [&](int64_t m0, int64_t n0) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ir = 8 * (2 * wave + i) + (lane >> 3);  // image row (k-contiguous images)
@@ -877,8 +1050,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
       }
     }
   }
+  };
+  set_offsets(m0, n0);
+  // PERSIST: the staging of a tile's last two K-tile steps already fetches the NEXT tile's first K-tiles (the ring never
+  // drains between tiles); ``stage_next`` says the offsets above belong to the next tile
+  bool has_next = false, stage_next = false;
+  bool in_loop = false;  // (ABL == 4, diagnostics: the loop's stages are skipped, the prologue's are not)
   auto stage = [&](int buf, int kind, int t) {  // kind: 0 A^0, 1 A^1, 2 B^0, 3 B^1; t: tile within the split
-    t = t < nt ? t : nt - 1;
+    if (ABL == 4 && in_loop) return;
+    if (PERSIST && stage_next) t -= nt;   // (the offsets were switched to the next tile: its K-tile 0 or 1; nt >= 2)
+    else t = t < nt ? t : nt - 1;
     const int kt = kt0 + t;
     const char* src = kind < 2 ? Abase + (int64_t)kt * (A_KS ? 128 * d.a_sk : 128) : Bbase + (int64_t)kt * (B_KS ? 128 * d.b_sk : 128);
     char* dst = smem + buf * P8_BUF + kind * P8_HALF + (2 * wave) * 1024;
@@ -916,6 +1097,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   bf16x8 ar[2][4], b0[4], b1[4];
 
   auto readA = [&](int bufoff, int a, int t) {
+    if constexpr (ABL == 2) return;
     if constexpr (A_KS) {
       const char* img = smem + bufoff + a * P8_HALF;
 #pragma unroll
@@ -945,6 +1127,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     }
   };
   auto readB = [&](int bufoff, int b, bf16x8 (&br)[4]) {
+    if constexpr (ABL == 2) return;
     if constexpr (B_KS) {
       const char* img = smem + bufoff + (2 + b) * P8_HALF;
 #pragma unroll
@@ -957,12 +1140,105 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   };
 #define P8_MMA(A_, B_, BR_)                                                                               \
   do {                                                                                                    \
+    if constexpr (ABL == 2) break;                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int mi = 0; mi < ((A_) == 0 ? 2 : MI1); ++mi) \
-        acc[2 * (A_) + mi][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[mi][kk], BR_[kk], acc[2 * (A_) + mi][B_], 0, 0, 0); \
+        acc[2 * (A_) + mi][B_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BR_[kk], ar[mi][kk], acc[2 * (A_) + mi][B_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                        \
   } while (0)
 
+  // one K-tile = phases 1..4 of the table on buffer OWN_ (phases 5..8 are the same with the buffers swapped).
+  // MID_: statement run between phase 2 and phase 3 (the persistent kernel switches its staging offsets to the next tile there)
+#define P8_KTILE(OWN_, T_, MID_)                                              \
+  do {                                                                        \
+    const int own = (OWN_), oth = own ^ 1;                                    \
+    const int ownoff = own * P8_BUF;                                          \
+    readB(ownoff, 0, b0);                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    readA(ownoff, 0, (T_));                                                   \
+    stage(oth, 3, (T_) + 1);                                                  \
+    p8_barrier();                                                             \
+    P8_MMA(0, 0, b0);                                                         \
+    p8_barrier();                                                             \
+                                                                              \
+    readB(ownoff, 1, b1);                                                     \
+    stage(oth, 1, (T_) + 1);                                                  \
+    if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                     \
+    p8_barrier();                                                             \
+    P8_MMA(0, 1, b1);                                                         \
+    p8_barrier();                                                             \
+    MID_;                                                                     \
+    readA(ownoff, 1, (T_));                                                   \
+    stage(own, 2, (T_) + 2);                                                  \
+    p8_barrier();                                                             \
+    P8_MMA(1, 1, b1);                                                         \
+    p8_barrier();                                                             \
+                                                                              \
+    stage(own, 0, (T_) + 2);                                                  \
+    if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                     \
+    p8_barrier();                                                             \
+    P8_MMA(1, 0, b0);                                                         \
+    p8_barrier();                                                             \
+  } while (0)
+
+  if constexpr (PERSIST) {
+    // ---- persistent form (gridDim.y == gridDim.z == 1, nt == P.ktiles >= 2): the K-tile stream runs on across tiles.
+    // During a tile's last two K-tile steps the stages fetch the next tile's K-tile 0 (whole) and the first-read half of
+    // its K-tile 1 - exactly what the prologue below fetches for the first tile - so between tiles the ring never drains and
+    // only the epilogue separates one tile's last MFMA from the next tile's first.  The epilogue's staging lives where no
+    // DMA is in flight: the A^1 / B^1 half-tiles of the buffer the last K-tile was read from (waves 0-3) and the 32 KiB
+    // above the ring (waves 4-7).
+    stage(0, 2, 0);
+    stage(0, 0, 0);
+    stage(0, 3, 0);
+    stage(0, 1, 0);
+    stage(1, 2, 1);
+    stage(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p8_barrier();
+    if (wr == 1) p8_barrier();  // this group runs one barrier behind
+    int g = 0;                  // K-tiles multiplied so far: the ring's parity
+    for (;;) {
+      int64_t nm0 = 0, nn0 = 0;
+      const int nslot = next_slot(slot + (int)gridDim.x, nm0, nn0);
+      has_next = nslot < P.slots;
+#pragma unroll
+      for (int i = 0; i < NMI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int t = 0; t < nt; ++t, ++g) {
+        // (t == nt - 2, after phase 2: every later stage of this tile's loop belongs to the next tile)
+        P8_KTILE(g & 1, t, if (has_next && t == nt - 2) { set_offsets(nm0, nn0); stage_next = true; });
+      }
+      stage_next = false;
+      if (wr == 0) p8_barrier();  // rejoin the other group: nobody reads the ring any more
+      {
+        const int last = (g - 1) & 1;  // buffer of the last K-tile: its A^1 / B^1 halves are not being refilled
+        char* E = wave < 4 ? smem + last * P8_BUF + (1 + 2 * (wave >> 1)) * P8_HALF + (wave & 1) * 8192
+                           : smem + 2 * P8_BUF + (wave - 4) * 8192;
+        if (!(P.dbg & 1)) {
+#pragma unroll
+          for (int mi = 0; mi < NMI; ++mi)
+            wide_epilogue<TC, (BM == 192 ? 2 : 1)>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
+        } else if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
+      }
+      if (!has_next) break;
+      slot = nslot;
+      m0 = nm0;
+      n0 = nn0;
+      p8_barrier();               // every wave is done with its staging image before the next stages land on it
+      if (wr == 1) p8_barrier();  // stagger again
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages
+    return;
+  } else {
+  const bool stamping = (P.dbg & 16) && blockIdx.x == 8 && blockIdx.y == 0 && wave == 0;  // diagnostics: where a tile's cycles go
+  unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+  if (stamping) ts[0] = stamp();
   if (nt > 0) {  // (uniform over the workgroup)
     // ---- prologue: tile 0 whole, the first-read half of tile 1
     stage(0, 2, 0);
@@ -974,45 +1250,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p8_barrier();
     if (wr == 1) p8_barrier();  // this group runs one barrier behind
+    if (stamping) ts[1] = stamp();
 
-    // one K-tile per iteration: phases 5..8 of the table are phases 1..4 with the buffers swapped
-    for (int t = 0; t < nt; ++t) {
-      const int own = t & 1, oth = own ^ 1;
-      const int ownoff = own * P8_BUF;
-      readB(ownoff, 0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      readA(ownoff, 0, t);
-      stage(oth, 3, t + 1);
-      p8_barrier();
-      P8_MMA(0, 0, b0);
-      p8_barrier();
-
-      readB(ownoff, 1, b1);
-      stage(oth, 1, t + 1);
-      if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      p8_barrier();
-      P8_MMA(0, 1, b1);
-      p8_barrier();
-
-      readA(ownoff, 1, t);
-      stage(own, 2, t + 2);
-      p8_barrier();
-      P8_MMA(1, 1, b1);
-      p8_barrier();
-
-      stage(own, 0, t + 2);
-      if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      p8_barrier();
-      P8_MMA(1, 0, b0);
-      p8_barrier();
-    }
+    // one K-tile per iteration
+    in_loop = true;
+    for (int t = 0; t < nt; ++t) P8_KTILE(t & 1, t, (void)0);
+    if (stamping) ts[2] = stamp();
     if (wr == 0) p8_barrier();  // rejoin the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages must land before LDS is reused
     p8_barrier();
+    if (stamping) ts[3] = stamp();
   }
-#undef P8_MMA
 
   if (P.dbg & 1) {  // diagnostics: no epilogue (keep the accumulators live)
     if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
@@ -1021,7 +1269,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   char* E = smem + wave * 8192;
 #pragma unroll
   for (int mi = 0; mi < NMI; ++mi)
-    wide_epilogue<TC>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
+    wide_epilogue<TC, (BM == 192 ? 2 : 1)>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
+  if (stamping) {
+    ts[4] = stamp();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[5] = stamp();
+    if (lane == 0)
+      for (int i = 0; i < 5; ++i) g_gemm_stamps[i] = ts[i + 1] - ts[i];
+  }
+  }
+#undef P8_KTILE
+#undef P8_MMA
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1039,6 +1297,7 @@ int launch_with_slabs(const FastParams& P, int splitk, hipStream_t stream, F&& l
   Q.split_c_stride = d.nbatch * d.M * d.N;
   Q.drop_thr = 0;
   Q.wide = d.N % 4 == 0;
+  Q.epi = epi_class(Q.d, Q.wide != 0);
   launch(Q);
   int rc = tmi_check_launch("tmi_gemm(split-K)");
   if (rc) return rc;
@@ -1084,20 +1343,24 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   const int vecC = 16 / (int)sizeof(TC);
   P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
+  P.epi = epi_class(d, P.wide != 0);
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
   P.split_c_stride = 0;
+  P.slots = 0;
   P.drop_thr = tmi_drop_thr(d.dropout_p);
   P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
   P.drop_scale = tmi_keep_scale(P.drop_thr);
   bool ws_split = false;
   auto kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG>;
+#ifdef TMI_GEMM_EXPERIMENTS
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && (CFG < 2 || CFG == 4 || CFG == 6)) {  // ablation builds exist for the bf16-out KC-A kernels only
     if ((dbg & 6) == 2) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 2>;
     if ((dbg & 6) == 4) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 4>;
     if (dbg == 8) kern = gemm_fast_kernel<TC, A_KS, B_KS, CFG, 8>;
     if (dbg & 14) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
+#endif
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<TC, A_KS, B_KS, CFG>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) {
@@ -1205,6 +1468,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   const int vecC = 16 / (int)sizeof(TC);
   P.wide = al16(d.C) && d.ldc % vecC == 0 && d.c_sb % vecC == 0 && (!d.aux_out || al16(d.aux_out)) &&
            (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % vecC == 0 && d.r_sb % vecC == 0));
+  P.epi = epi_class(d, P.wide != 0);
   static const int dbg8 = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg8;
   P.split_c_stride = 0;
@@ -1256,7 +1520,31 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
       if (want > 1) splitk = (int)want;
     }
   }
+  P.slots = 8 * P.ptm * P.ptn;
+  // More tiles than CUs (bf16-output forward / dgrad launches of two or three rounds): the persistent form - 256 workgroups
+  // walk the slots, the K-tile ring runs on from one tile into the next (no prologue after the first tile) and the epilogue
+  // is staged outside the ring.  TMI_GEMM_P8_PERSIST=0 restores one workgroup per tile.
+  if constexpr (!(A_KS && B_KS)) {
+    static const int persist = [] { const char* e = getenv("TMI_GEMM_P8_PERSIST"); return e ? atoi(e) : 1; }();
+    if (persist && splitk == 1 && d.nbatch == 1 && P.slots > 256 && P.ktiles >= 2) {
+      constexpr int LDS_P = 2 * P8_BUF + 32768;
+      static const hipError_t attr_p = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p8_kernel<TC, A_KS, B_KS, BM, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
+      if (attr_p == hipSuccess) {
+        hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM, true>), dim3(256), dim3(512), LDS_P, stream, P);
+        return tmi_check_launch("tmi_gemm(p8 persistent)");
+      }
+    }
+  }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
+  if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && BM == 192) {  // diagnostics: TMI_GEMM_DBG & 6 = 2 no MFMA / reads, 4 no staging in the loop
+    if ((dbg8 & 6) && splitk == 1) {
+      auto kern = (dbg8 & 6) == 2 ? gemm_p8_kernel<TC, A_KS, B_KS, BM, false, 2> : gemm_p8_kernel<TC, A_KS, B_KS, BM, false, 4>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * P8_BUF);
+      hipLaunchKernelGGL(kern, grid, dim3(512), 2 * P8_BUF, stream, P);
+      return tmi_check_launch("tmi_gemm(p8 ablation)");
+    }
+  }
   if (splitk > 1) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
     hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), grid, dim3(512), 2 * P8_BUF, stream, Q);
   });
@@ -1284,17 +1572,21 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   // too few 128x128 tiles to occupy the chip (and not a split-K weight gradient): 64x64 tiles
   const int64_t mid_tiles = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.nbatch;
   const bool small = !wgrad_like && mid_tiles < 200 && d.M >= 64 && d.N >= 64;
+  // (configurations 0-3 and 7-10 are round-1/2 experiments no rule picks: built only with -DTMI_GEMM_EXPERIMENTS - they were
+  // 60 % of this file's compile time)
+#ifdef TMI_GEMM_EXPERIMENTS
   if (force == 0) return launch_cfg<TC, A_KS, B_KS, 0>(d, stream);
   if (force == 1) return launch_cfg<TC, A_KS, B_KS, 1>(d, stream);
   if (force == 2) return launch_cfg<TC, A_KS, B_KS, 2>(d, stream);
   if (force == 3) return launch_cfg<TC, A_KS, B_KS, 3>(d, stream);
-  if (force == 4) return launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
-  if (force == 5) return launch_cfg<TC, A_KS, B_KS, 5>(d, stream);
-  if (force == 6) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
   if (force == 7) return launch_cfg<TC, A_KS, B_KS, 7>(d, stream);
   if (force == 8) return launch_cfg<TC, A_KS, B_KS, 8>(d, stream);
   if (force == 9) return launch_cfg<TC, A_KS, B_KS, 9>(d, stream);
   if (force == 11) return launch_cfg<TC, A_KS, B_KS, 10>(d, stream);
+#endif
+  if (force == 4) return launch_cfg<TC, A_KS, B_KS, 4>(d, stream);
+  if (force == 5) return launch_cfg<TC, A_KS, B_KS, 5>(d, stream);
+  if (force == 6) return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
   if (force == 12 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
   if (force == 13 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
   if (force == 15 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
@@ -1331,7 +1623,9 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256) {
       // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
       static const int no192 = [] { const char* e = getenv("TMI_GEMM_NO_P8_192"); return e ? atoi(e) : 0; }();
-      static const int short192 = [] { const char* e = getenv("TMI_GEMM_P8_192_SHORTK"); return e ? atoi(e) : 0; }();
+      // (round 4: on by default - with the lean epilogue the 192-row tile beats the two co-resident 128x128 workgroups in the step
+      // as well: fc1 forward + GELU + saved pre-activation 115 -> 95 us, fc2 dgrad + GELU' 113 -> 97 us, step 8.22 -> 8.16 ms)
+      static const int short192 = [] { const char* e = getenv("TMI_GEMM_P8_192_SHORTK"); return e ? atoi(e) : 1; }();
       const int64_t tn = (d.N + 255) / 256;
       const int64_t t256 = ((d.M + 255) / 256) * tn * d.nbatch, t192 = ((d.M + 191) / 192) * tn * d.nbatch;
       const int64_t c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
@@ -1360,6 +1654,13 @@ int launch_out(const tmi_gemm_desc& d, hipStream_t stream) {
 
 // diagnostics: copies the ABL == 8 phase counters (host-synchronous)
 extern "C" int tmi_debug_gemm_stamps(unsigned long long* out5) {
+  static const int epi = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? (atoi(e) & 32) : 0; }();
+  if (epi) {  // (TMI_GEMM_DBG & 32: the stamps inside wide_epilogue instead; reading them re-arms the probe)
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, got[8];
+    if (hipMemcpyFromSymbol(got, HIP_SYMBOL(g_epi_stamps), sizeof(got)) != hipSuccess) return -2;
+    for (int i = 0; i < 5; ++i) out5[i] = got[i];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_epi_stamps), z, sizeof(z)) == hipSuccess ? 0 : -2;
+  }
   return hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_stamps), 5 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // the FFN GEMMs stays under the store time.  cdf and pdf share the one exponential.
 __device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& pdf) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);  // v_rcp_f32 (1 ulp): __frcp_rn expands to the ~10-instruction IEEE division
   const float e = __expf(-z * z);  // = exp(-x^2/2)
   float p = 1.061405429f;
   p = p * t - 1.453152027f;
