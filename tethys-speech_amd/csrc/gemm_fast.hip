@@ -219,6 +219,16 @@ template <> struct Vec8<float> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = r[i];
   }
+  static __device__ __forceinline__ raw_t pack(const float (&v)[8]) {
+    raw_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = v[i];
+    return r;
+  }
+  static __device__ __forceinline__ void store_raw(float* p, const raw_t& r) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{r[0], r[1], r[2], r[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{r[4], r[5], r[6], r[7]};
+  }
   static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
@@ -236,6 +246,13 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
   }
+  static __device__ __forceinline__ raw_t pack(const float (&v)[8]) {
+    raw_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    return r;
+  }
+  static __device__ __forceinline__ void store_raw(bf16_t* p, const raw_t& r) { *reinterpret_cast<bf16x8*>(p) = r; }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -268,6 +285,7 @@ __device__ __forceinline__ int epi_off(int row, int col) { return row * 256 + ((
 // owns 8 consecutive columns of one row per pass (16-byte accesses throughout).
 template <typename TC, int CLS, int AHEAD>
 __device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, int64_t mw, int64_t nw, int64_t bz, int lane) {
+  asm volatile("" : "+v"(lane));  // (opaque: nothing below is to be hoisted above the K loop of a persistent kernel)
   const tmi_gemm_desc& d = P.d;
   typedef typename Vec8<TC>::raw_t raw_t;
   const int chunk = lane & 7, rsub = lane >> 3;
@@ -336,6 +354,8 @@ __device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, in
           for (int i = 0; i < 8; ++i) v[i] += t[i];
         }
       }
+      // (plain stores: non-temporal ones make this launch 5-8 % faster alone - the C stream no longer evicts the operand
+      // panels from L2 - and the STEP 0.15 ms slower: the consumer finds C neither in L2 nor in the Infinity Cache)
       Vec8<TC>::store(cp + (pp + j) * step, v);
     }
   }
@@ -349,6 +369,7 @@ __device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, in
 template <typename TC, int AHEAD = 2>
 __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16& a0, const f32x16& a1, char* E,
                                               int64_t mw, int64_t nw, int64_t bz, int lane, bool atomic) {
+  asm volatile("" : "+v"(lane));  // (opaque: see lean_rows)
   const tmi_gemm_desc& d = P.d;
   const bool st = (P.dbg & 32) && blockIdx.x == 8 && threadIdx.x < 64;
   unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0;
@@ -990,7 +1011,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     if (!decode(slot, m0, n0)) return;
   }
   const int64_t bz = blockIdx.z;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, lane_id = lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   // this split's K-tiles [kt0, kt0 + nt)
@@ -1014,6 +1035,10 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   unsigned offA[2][2], offB[2][2];
   int krs[2];  // k-row of this lane's two loads (k-strided images)
   auto set_offsets = [&](int64_t m0, int64_t n0) {
+  // (an opaque copy of the lane id: the persistent kernel calls this inside its loop, and without it the compiler keeps every
+  // lane-derived term below alive across the whole K loop - ~40 registers the loop needs for the deferred stores)
+  int lane = lane_id;
+  asm volatile("" : "+v"(lane));
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ir = 8 * (2 * wave + i) + (lane >> 3);  // image row (k-contiguous images)
@@ -1163,8 +1188,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
                                                                               \
     readB(ownoff, 1, b1);                                                     \
     stage(oth, 1, (T_) + 1);                                                  \
-    if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                     \
+    wait_vmcnt<(BM == 256 ? 8 : 7)>();                                        \
     p8_barrier();                                                             \
     P8_MMA(0, 1, b1);                                                         \
     p8_barrier();                                                             \
@@ -1176,8 +1200,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     p8_barrier();                                                             \
                                                                               \
     stage(own, 0, (T_) + 2);                                                  \
-    if constexpr (BM == 256) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                     \
+    wait_vmcnt<(BM == 256 ? 6 : 5)>();                                        \
     p8_barrier();                                                             \
     P8_MMA(1, 0, b0);                                                         \
     p8_barrier();                                                             \
@@ -1200,6 +1223,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     p8_barrier();
     if (wr == 1) p8_barrier();  // this group runs one barrier behind
     int g = 0;                  // K-tiles multiplied so far: the ring's parity
+    // (Round 4, measured and removed: the finished rows of a tile held back in registers - two of a wave's three pieces fit -
+    // and stored one per K-tile step under the NEXT tile's MFMAs, all waves at the head of the step or one wave per phase.
+    // The launches got 8-10 us SLOWER (fc1 forward 81 -> 88, fc2 dgrad 76 -> 87): the CU's vector-memory pipe that takes a
+    // store (~73 cycles per wave-instruction whatever its width: the 7 k-cycle epilogue of a 96 KiB tile IS 96 of them) is
+    // the pipe the K loop's LDS-DMA keeps busy, so a store moved into the loop delays the staging it was meant to hide
+    // under: profiles/r04_gemm_deferred_stores_ab.txt.)
     for (;;) {
       int64_t nm0 = 0, nn0 = 0;
       const int nslot = next_slot(slot + (int)gridDim.x, nm0, nn0);
@@ -1220,11 +1249,17 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
         const int last = (g - 1) & 1;  // buffer of the last K-tile: its A^1 / B^1 halves are not being refilled
         char* E = wave < 4 ? smem + last * P8_BUF + (1 + 2 * (wave >> 1)) * P8_HALF + (wave & 1) * 8192
                            : smem + 2 * P8_BUF + (wave - 4) * 8192;
-        if (!(P.dbg & 1)) {
-#pragma unroll
-          for (int mi = 0; mi < NMI; ++mi)
-            wide_epilogue<TC, (BM == 192 ? 2 : 1)>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
-        } else if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
+        const int64_t mw0 = m0 + wr * WR, nw0 = n0 + wc * 64;
+        if (P.dbg & 1) {
+          if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
+        } else {
+          // (written out: LLVM's pragma-unroll threshold declines four copies of the fp32 epilogue, and a rolled loop
+          // indexes acc dynamically - 576 B of scratch per lane in the weight-gradient kernels)
+          wide_epilogue<TC, 2>(P, acc[0][0], acc[0][1], E, mw0, nw0, bz, lane, false);
+          wide_epilogue<TC, 2>(P, acc[1][0], acc[1][1], E, mw0 + 32, nw0, bz, lane, false);
+          wide_epilogue<TC, 2>(P, acc[2][0], acc[2][1], E, mw0 + 64, nw0, bz, lane, false);
+          if constexpr (NMI == 4) wide_epilogue<TC, 2>(P, acc[NMI - 1][0], acc[NMI - 1][1], E, mw0 + 96, nw0, bz, lane, false);
+        }
       }
       if (!has_next) break;
       slot = nslot;
@@ -1267,9 +1302,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     return;
   }
   char* E = smem + wave * 8192;
-#pragma unroll
-  for (int mi = 0; mi < NMI; ++mi)
-    wide_epilogue<TC, (BM == 192 ? 2 : 1)>(P, acc[mi][0], acc[mi][1], E, m0 + wr * WR + mi * 32, n0 + wc * 64, bz, lane, false);
+  {
+    const int64_t mw0 = m0 + wr * WR, nw0 = n0 + wc * 64;  // (written out: see the persistent form)
+    wide_epilogue<TC, 2>(P, acc[0][0], acc[0][1], E, mw0, nw0, bz, lane, false);
+    wide_epilogue<TC, 2>(P, acc[1][0], acc[1][1], E, mw0 + 32, nw0, bz, lane, false);
+    wide_epilogue<TC, 2>(P, acc[2][0], acc[2][1], E, mw0 + 64, nw0, bz, lane, false);
+    if constexpr (NMI == 4) wide_epilogue<TC, 2>(P, acc[NMI - 1][0], acc[NMI - 1][1], E, mw0 + 96, nw0, bz, lane, false);
+  }
   if (stamping) {
     ts[4] = stamp();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
