@@ -1659,7 +1659,11 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if constexpr (!A_KS) {
     static const int no_p8 = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
     const bool light_epi = !d.aux_in && !d.aux_out && !d.act && d.N <= 1024;
-    if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && d.M >= 2048 && d.N >= 256) {
+    // (round 4: batched launches count their batches - the conv2 forward is 8 x [1500, 768] x K 2304 and ran 148 us on the
+    // 2-stage 256x256 kernel)
+    static const int p8_all = [] { const char* e = getenv("TMI_GEMM_P8_ALL"); return e ? atoi(e) : 0; }();  // (off: level or +0.04 ms in the step, profiles/r04_step_ab_p8_all.txt)
+    const bool m_ok = d.M >= 2048 || (p8_all && d.M >= 1024 && d.M * d.nbatch >= 4096);
+    if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && m_ok && d.N >= 256) {
       // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
       static const int no192 = [] { const char* e = getenv("TMI_GEMM_NO_P8_192"); return e ? atoi(e) : 0; }();
       // (round 4: on by default - with the lean epilogue the 192-row tile beats the two co-resident 128x128 workgroups in the step
@@ -1670,7 +1674,9 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
       const int64_t c256 = ((t256 + 255) / 256) * 256, c192 = ((t192 + 255) / 256) * 192;
       // (the 192-row loop does ~10 % less per cycle - two of its four phases issue half the MFMAs - so it has to save more than that)
       const bool win192 = !no192 && c192 * 100 <= c256 * 85;
-      const bool long_k = d.K >= 1024 || (!B_KS && light_epi);
+      // (round 4, TMI_GEMM_P8_ALL=1: short K too - with the lean epilogue the eight-phase kernel wins there as well: qkv forward
+      // 12000 x 2304 x 768 65.8 us on the 2-stage 256x256 kernel in the step, 56 us here)
+      const bool long_k = p8_all || d.K >= 1024 || (!B_KS && light_epi);
       // short K with heavy epilogues / k-strided weights (TMI_GEMM_P8_192_SHORTK=1, off): alone and with a plain epilogue the
       // 192-row tile wins there too (fc1 forward 12000 x 3072 x 768: 100.6 -> 80.3 us), but with the real GELU + aux epilogues
       // in the step the one-workgroup-per-CU kernel loses to two co-resident 128x128 workgroups: 9.06 -> 9.29 ms/step

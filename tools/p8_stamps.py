@@ -17,3 +17,15 @@ for M, N, K in ((768, 3072, 768), (12000, 3072, 768), (12000, 768, 3072)):
     out = (ctypes.c_ulonglong * 5)()
     fn(out)
     print(f"M {M} N {N} K {K}: prologue {out[0]} loop {out[1]} ({out[1] / (K // 64):.0f}/K-tile) rejoin+drain {out[2]} epilogue {out[3]} store drain {out[4]} cycles")
+if os.environ.get("STAMP_WGRAD"):
+    # weight-gradient shapes: C[M,N] fp32 = X^T dY, X [K,M], dY [K,N] (both k-strided), split-K through the workspace
+    for M, N, K in ((768, 3072, 12000), (768, 2304, 12000), (768, 768, 12000)):
+        X = torch.randn(K, M, device=dev).to(bf)
+        dY = torch.randn(K, N, device=dev).to(bf)
+        Cw = torch.zeros(M, N, device=dev, dtype=torch.float32)
+        for _ in range(5):
+            ops.gemm(X, dY, Cw, M, N, K, 1, M, N, 1, N, splitk=0)
+        torch.cuda.synchronize()
+        out = (ctypes.c_ulonglong * 5)()
+        fn(out)
+        print(f"wgrad M {M} N {N} K {K}: prologue {out[0]} loop {out[1]} rejoin+drain {out[2]} epilogue {out[3]} store drain {out[4]} cycles")
