@@ -220,6 +220,65 @@ def test_gemm_eight_phase_paths(dev, M, N, K, b_kn):
     assert rel_err(Cm, ref) <= 1.5e-2
 
 
+@pytest.mark.parametrize("cls", ["simple", "gelu_aux", "scale", "auxin", "resid_drop", "acc", "generic"])
+@pytest.mark.parametrize("M,N,K,b_kn", [(12000, 3072, 768, True),     # 756 tiles of 192 x 256: the PERSISTENT kernel, three per CU
+                                        (12000, 3072, 768, False),    # the same as a dgrad (k-contiguous B)
+                                        (5000, 2240, 256, False)])    # ragged both ways: 5000 = 26 * 192 + 8, 2240 = 8 * 256 + 192
+def test_gemm_lean_epilogue_classes_and_persistent_tiles(dev, cls, M, N, K, b_kn):
+    """Round 4: the eight-phase kernel's persistent form (more tiles than CUs: the K-tile ring runs on across tiles) and
+    the class-specialised interior epilogue (gemm_fast.hip epi_class / lean_rows: EPI_SIMPLE with bias, q scale, GELU +
+    saved pre-activation; EPI_AUXIN = x GELU'(aux_in); EPI_RESID = bias, dropout, + residual; EPI_ACC = C +=; everything
+    else and every edge piece through the generic code) against an fp64 reference of the same bf16 operands.  Every
+    row and column is checked, so a tile the persistent walk skipped or wrote twice, or an edge piece taking the interior
+    path, shows."""
+    ops = _ops()
+    bf = torch.bfloat16
+    A = rnd((M, K), bf, dev, 21)
+    Bm = rnd((K, N), bf, dev, 22, 0.1)
+    bias = rnd((N,), torch.float32, dev, 23)
+    X = rnd((M, N), bf, dev, 24)
+    Cm = torch.empty((M, N), dtype=bf, device=dev)
+    if b_kn:
+        Bop, b_sk, b_sn = Bm, N, 1
+    else:
+        Bop, b_sk, b_sn = Bm.t().contiguous(), 1, K
+    acc = A.double() @ Bm.double()
+    gelu = lambda v: 0.5 * v * (1 + torch.erf(v / math.sqrt(2)))
+    gelu_grad = lambda u: 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+    kw, aux = {}, None
+    if cls == "simple":
+        kw, ref = dict(bias=bias), acc + bias.double()
+    elif cls == "gelu_aux":
+        aux = torch.empty_like(Cm)
+        kw, ref = dict(bias=bias, act=1, aux_out=aux), gelu(acc + bias.double())
+    elif cls == "scale":   # the q columns of a fused qkv projection: bias, then scale on the first 256 columns
+        ref = acc + bias.double()
+        ref[:, :256] *= 0.125
+        kw = dict(bias=bias, scale_cols=256, scale=0.125)
+    elif cls == "auxin":
+        kw, ref = dict(aux_in=X), acc * gelu_grad(X.double())
+    elif cls == "resid_drop":
+        p, seed = 0.1, 99
+        from oracle import dropout as DO
+        keep = torch.from_numpy(DO.keep_flat(seed, M, N, p)).to(dev)
+        ref = (acc + bias.double()) * keep.double() * DO.keep_scale(p) + X.double()
+        kw = dict(bias=bias, resid=X, r_ld=N, dropout_p=p, dropout_seed=seed)
+    elif cls == "acc":
+        Cm.copy_(X)
+        kw, ref = dict(accumulate=True), acc + X.double()
+    else:                  # a combination outside the classes: GELU + residual (the conv stem's epilogue)
+        aux = torch.empty_like(Cm)
+        kw, ref = dict(bias=bias, act=1, aux_out=aux, resid=X, r_ld=N), gelu(acc + bias.double()) + X.double()
+    ops.gemm(A, Bop, Cm, M, N, K, K, 1, b_sk, b_sn, N, **kw)
+    assert rel_err(Cm, ref) <= 1.5e-2, cls
+    # row- and column-wise: no tile may be off (a skipped tile is an O(1) relative error of ITS rows only)
+    err_r = ((Cm.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-6)).max().item()
+    err_c = ((Cm.double() - ref).norm(dim=0) / ref.norm(dim=0).clamp_min(1e-6)).max().item()
+    assert err_r <= 3e-2 and err_c <= 3e-2, (cls, err_r, err_c)
+    if aux is not None:
+        assert rel_err(aux, acc + bias.double()) <= 1.5e-2
+
+
 @pytest.mark.parametrize("T,Kin,N", [(4128, 768, 2304), (4640, 1544, 1160), (4128, 256, 768), (8200, 128, 384)])
 def test_gemm_weight_gradient_paths(dev, T, Kin, N):
     """dW[Kin, N] = X^T dY over T tokens (T % 64 = 32 or 8: K tail), library-chosen split-K with the
