@@ -298,7 +298,8 @@ extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (d.nbatch2 == 1 && d.in_dtype == TMI_BF16 && (d.out_dtype == TMI_BF16 || d.out_dtype == TMI_F32) && !fast_disabled()) {
+  if ((d.nbatch2 == 1 || d.in_dtype == TMI_F32) && (d.in_dtype == TMI_BF16 || d.in_dtype == TMI_F32) &&
+      (d.out_dtype == TMI_BF16 || d.out_dtype == TMI_F32) && !fast_disabled()) {
     int rc = 0;
     if (tmi_gemm_fast_try(d, s, &rc)) return rc;
   }

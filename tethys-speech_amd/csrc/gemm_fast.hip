@@ -1695,6 +1695,247 @@ int launch_out(const tmi_gemm_desc& d, hipStream_t stream) {
   return d.out_dtype == TMI_F32 ? launch_fast<float, A_KS, B_KS>(d, stream) : launch_fast<bf16_t, A_KS, B_KS>(d, stream);
 }
 
+
+// =====================================================================================
+// fp32 operands (the parity mode, --precision fp32: the reference's own arithmetic width).  Round 4: the same staging
+// as the bf16 kernels instead of the generic kernel of gemm.hip (single LDS buffer, register staging, 4-way bank
+// conflicts on its ds_read_b32 fragments, element-wise epilogue: 40-68 TF/s of the 157 TF/s exact-fp32 MFMA roof).
+// 128 x 128 tile, 4 waves (2 x 2) of 64 x 64, K in slabs of 32 floats = the 128-byte rows of the bf16 images:
+//   KC operand (k-contiguous rows): byte for byte the bf16 KC image and its DMA (the fp32 matrix is staged through its
+//      bf16 view: 2 x the element strides); a 16-byte fragment read is 4 consecutive k of one row, and lane half h takes
+//      chunk 2 j + h, so MFMA step (j, e) multiplies k = 8 j + 4 h + e - any pairing works as long as both operands use it;
+//   KS operand (k-strided, contiguous columns): [32 k][64 columns] sub-images of 256-byte rows, filled lane-linearly by
+//      the DMA (4 k-rows per wave-instruction); a fragment element is one ds_read_b32, 32 lanes on 32 consecutive columns
+//      (conflict-free without a swizzle).
+// v_mfma_f32_32x32x2_f32 takes 64 cycles: a slab is 64 MFMAs = 4096 cycles per wave against 32 KiB of staging and at most
+// 48 LDS reads, so two co-resident workgroups (64 KiB of LDS each) keep the matrix pipe busy with the plain two-stage loop.
+template <typename TC, bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const FastParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16 KiB | B 16 KiB]
+  const tmi_gemm_desc& d = P.d;
+  const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+  int ltm, ltn;
+  if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
+  else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
+  const int tm = (xcd / P.xn) * P.ptm + ltm, tn = (xcd % P.xn) * P.ptn + ltn;
+  if (tm >= P.tiles_m || tn >= P.tiles_n) return;
+  const int64_t m0 = (int64_t)tm * 128, n0 = (int64_t)tn * 128;
+  // two batch levels (the parity mode's attention products: batch rows x heads): z = b2 * nbatch + b1
+  const int64_t b2 = d.nbatch2 > 1 ? (int64_t)blockIdx.z / d.nbatch : 0, bz = (int64_t)blockIdx.z - b2 * d.nbatch;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int total_it = (int)d.kbatch * P.ktiles;
+  const int nsplit = gridDim.y;
+  const int per = (total_it + nsplit - 1) / nsplit;
+  const int it0 = blockIdx.y * per;
+  const int nt = min(total_it, it0 + per) - it0;
+  const float* Abase = reinterpret_cast<const float*>(d.A) + bz * d.a_sb + b2 * d.a_sb2;
+  const float* Bbase = reinterpret_cast<const float*>(d.B) + bz * d.b_sb + b2 * d.b_sb2;
+  // K tail (K % 4 == 0, host-checked; 1500 keys = 46 slabs + 28): the last slab's fetches are clamped inside the operands
+  // (finite, valid data) and the k >= kvalid part of the A image is zeroed before the MFMAs read it
+  const int kvalid = (int)(d.K - (int64_t)(P.ktiles - 1) * 32);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // KS staging: 128 columns x 32 k = two [32 k][64 col] sub-images; wave-instruction j (16 per operand, 4 per wave) covers
+  // k-rows 4 (j & 7) .. + 3 of sub-image j >> 3; a lane fetches 4 consecutive columns (clamped inside the operand)
+  auto stage_ks32 = [&](const float* base, int64_t s_k, int64_t col0, int64_t ncols, int64_t k0, char* img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * wave + i;
+      const int kr = 4 * (j & 7) + (lane >> 4);
+      int64_t gc = col0 + (j >> 3) * 64 + (lane & 15) * 4;
+      gc = gc + 4 <= ncols ? gc : ncols - 4;
+      int64_t gk = k0 + kr;
+      gk = gk < d.K ? gk : d.K - 1;
+      glds16(base + gk * s_k + gc, img + j * 1024);
+    }
+  };
+  // k-contiguous rows: the bf16 kernels' KC image byte for byte (stage_kc), with the K clamp
+  auto stage_kc32 = [&](const float* base, int64_t s_row, int64_t row0, int64_t nrows, int64_t k0, char* img) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 4 * wave + i;
+      const int rr = 8 * j + (lane >> 3);
+      const int c = (lane & 7) ^ ((rr >> 1) & 7);
+      int64_t grow = row0 + rr;
+      grow = grow < nrows ? grow : nrows - 1;
+      int64_t gk = k0 + 4 * c;
+      gk = gk + 4 <= d.K ? gk : d.K - 4;
+      glds16(base + grow * s_row + gk, img + j * 1024);
+    }
+  };
+  auto stage = [&](int it, int buf) {
+    const int kb = it / P.ktiles, kt = it - kb * P.ktiles;
+    char* As = smem + buf * 32768;
+    char* Bs = As + 16384;
+    if constexpr (A_KS) stage_ks32(Abase + kb * d.a_skb, d.a_sk, m0, P.a_cols_rd, (int64_t)kt * 32, As);
+    else stage_kc32(Abase + kb * d.a_skb, d.a_sm, m0, d.M, (int64_t)kt * 32, As);
+    if constexpr (B_KS) stage_ks32(Bbase + kb * d.b_skb, d.b_sk, n0, P.b_cols_rd, (int64_t)kt * 32, Bs);
+    else stage_kc32(Bbase + kb * d.b_skb, d.b_sn, n0, d.N, (int64_t)kt * 32, Bs);
+  };
+  auto zero_tail = [&](int it, int buf) {  // (uniform; the slab has landed and the barrier has been passed)
+    if (kvalid < 32 && (it % P.ktiles) == P.ktiles - 1) {
+      char* As = smem + buf * 32768;
+      if constexpr (A_KS) {   // k-rows kvalid .. 31 of both [32 k][256 B] sub-images
+        for (int idx = threadIdx.x; idx < 2 * (32 - kvalid) * 16; idx += 256) {
+          const int img = idx / ((32 - kvalid) * 16), rem = idx % ((32 - kvalid) * 16);
+          *reinterpret_cast<u32x4*>(As + img * 8192 + kvalid * 256 + rem * 16) = u32x4{0u, 0u, 0u, 0u};
+        }
+      } else {                // chunks kvalid / 4 .. 7 of every row, at their swizzled places
+        const int nch = 8 - kvalid / 4;
+        for (int idx = threadIdx.x; idx < 128 * nch; idx += 256) {
+          const int row = idx / nch, c = kvalid / 4 + idx % nch;
+          *reinterpret_cast<u32x4*>(As + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+      __syncthreads();
+    }
+  };
+  const int r = lane & 31, h = lane >> 5;
+  auto mma = [&](const char* As, const char* Bs) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {   // k = 8 jj .. 8 jj + 7 of the slab: lane half h holds 8 jj + 4 h + e
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (A_KS) {
+          const int col = wr * 64 + i * 32 + r;
+          const char* p0 = As + (col >> 6) * 8192 + (col & 63) * 4 + (8 * jj + 4 * h) * 256;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[i][e] = *reinterpret_cast<const float*>(p0 + e * 256);
+        } else {
+          const bf16x8 t = frag_kc(As, wr * 64 + i * 32 + r, jj, h);
+          a[i] = *reinterpret_cast<const f32x4*>(&t);
+        }
+        if constexpr (B_KS) {
+          const int col = wc * 64 + i * 32 + r;
+          const char* p0 = Bs + (col >> 6) * 8192 + (col & 63) * 4 + (8 * jj + 4 * h) * 256;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b[i][e] = *reinterpret_cast<const float*>(p0 + e * 256);
+        } else {
+          const bf16x8 t = frag_kc(Bs, wc * 64 + i * 32 + r, jj, h);
+          b[i] = *reinterpret_cast<const f32x4*>(&t);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)   // (operands swapped: the accumulator is the C^T block wide_epilogue takes)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[ni][e], a[mi][e], acc[mi][ni], 0, 0, 0);
+    }
+  };
+  if (nt > 0) {
+    stage(it0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (t + 1 < nt) stage(it0 + t + 1, buf ^ 1);   // the next slab's DMA flies under this slab's 64 MFMAs
+      zero_tail(it0 + t, buf);
+      const char* As = smem + buf * 32768;
+      mma(As, As + 16384);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  const bool atomic = nsplit > 1;
+  char* E = smem + wave * 8192;
+  if (b2 == 0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      wide_epilogue<TC, 2>(P, acc[p][0], acc[p][1], E, m0 + wr * 64 + p * 32, n0 + wc * 64, bz, lane, atomic);
+  } else {  // (outer batches carry no bias / aux / residual terms: only C moves)
+    FastParams Q = P;
+    Q.d.C = reinterpret_cast<TC*>(d.C) + b2 * d.c_sb2;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      wide_epilogue<TC, 2>(Q, acc[p][0], acc[p][1], E, m0 + wr * 64 + p * 32, n0 + wc * 64, bz, lane, atomic);
+  }
+}
+
+template <bool A_KS, bool B_KS>
+int launch_f32(const tmi_gemm_desc& d, hipStream_t stream) {
+  FastParams P;
+  P.d = d;
+  P.tiles_m = (int)((d.M + 127) / 128);
+  P.tiles_n = (int)((d.N + 127) / 128);
+  P.ktiles = (int)((d.K + 31) / 32);
+  P.a_cols_rd = (d.M + 3) / 4 * 4;
+  P.b_cols_rd = (d.N + 3) / 4 * 4;
+  P.wide = al16(d.C) && d.ldc % 4 == 0 && d.c_sb % 4 == 0 && (!d.aux_out || al16(d.aux_out)) &&
+           (!d.aux_in || al16(d.aux_in)) && (!d.resid || (al16(d.resid) && d.r_ld % 4 == 0 && d.r_sb % 4 == 0));
+  P.epi = epi_class(d, P.wide != 0);
+  static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
+  P.dbg = dbg;
+  P.split_c_stride = 0;
+  P.slots = 0;
+  P.drop_thr = tmi_drop_thr(d.dropout_p);
+  P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
+  P.drop_scale = tmi_keep_scale(P.drop_thr);
+  auto kern = gemm_f32_kernel<float, A_KS, B_KS>;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  if (attr != hipSuccess) {
+    tmi_set_error("tmi_gemm(f32): cannot raise the dynamic LDS limit");
+    return TMI_ERR_LAUNCH;
+  }
+  // XCD partition with the fewest padded workgroups (see launch_cfg); an fp32 operand share is twice the bf16 one
+  int aim = 1;
+  while (aim < 8 && (double)d.K * (double)d.kbatch * ((double)d.N / aim) * 4.0 > 2.0 * 1048576.0 && P.tiles_n >= 2 * aim) aim *= 2;
+  int xn = aim;
+  int64_t best = -1;
+  int best_dist = 0;
+  for (int cand = 1; cand <= 8; cand *= 2) {
+    const int64_t padded = (int64_t)((P.tiles_m + 8 / cand - 1) / (8 / cand)) * ((P.tiles_n + cand - 1) / cand);
+    int dist = 0;
+    for (int v = cand; v < aim; v *= 2) ++dist;
+    for (int v = aim; v < cand; v *= 2) ++dist;
+    if (best < 0 || padded < best || (padded == best && dist < best_dist)) {
+      best = padded;
+      best_dist = dist;
+      xn = cand;
+    }
+  }
+  P.xn = xn;
+  P.xm = 8 / xn;
+  P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
+  P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+  P.walk_m = walk_along_m(d, P.xm, P.xn);
+  // split-K (library-chosen, weight-gradient shapes): through workspace slabs when there is a workspace, fp32 atomics else
+  int splitk = d.splitk > 1 ? d.splitk : 1;
+  bool ws_split = false;
+  if (d.splitk == 0 && d.nbatch2 <= 1 && !d.bias && !d.accumulate && !d.act && !d.aux_out && !d.aux_in && !d.resid && d.scale_cols <= 0) {
+    const int64_t wgs = (int64_t)8 * P.ptm * P.ptn * d.nbatch;
+    const int64_t its = (int64_t)d.kbatch * P.ktiles;
+    int64_t want = 512 / wgs;
+    if (want > its / 8) want = its / 8;
+    const int64_t slab_bytes = d.M * d.N * d.nbatch * 4;
+    const bool use_ws = d.workspace && (reinterpret_cast<uintptr_t>(d.workspace) & 15) == 0 && 2 * slab_bytes <= d.workspace_bytes;
+    if (use_ws) {
+      if (want > 8) want = 8;
+      if (want > d.workspace_bytes / slab_bytes) want = d.workspace_bytes / slab_bytes;
+      ws_split = want > 1;
+    } else if (want > 4) want = 4;
+    splitk = want < 1 ? 1 : (int)want;
+  }
+  dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)(d.nbatch * (d.nbatch2 > 1 ? d.nbatch2 : 1)));
+  if (ws_split) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+    hipLaunchKernelGGL(kern, grid, dim3(256), 65536, stream, Q);
+  });
+  hipLaunchKernelGGL(kern, grid, dim3(256), 65536, stream, P);
+  return tmi_check_launch("tmi_gemm(f32)");
+}
+
 }  // namespace
 
 // diagnostics: copies the ABL == 8 phase counters (host-synchronous)
@@ -1711,6 +1952,21 @@ extern "C" int tmi_debug_gemm_stamps(unsigned long long* out5) {
 
 // Returns 1 and sets *rc if the fast path took the GEMM, 0 if the generic kernel must run.
 int tmi_gemm_fast_try(const tmi_gemm_desc& d, hipStream_t stream, int* rc) {
+  if (d.in_dtype == TMI_F32) {  // the parity mode's GEMMs: fp32 in, fp32 out, whole 32-float slabs, 16-byte aligned operands
+    static const int off = [] { const char* e = getenv("TMI_GEMM_F32_FAST"); return e && atoi(e) == 0; }();
+    if (off || d.out_dtype != TMI_F32 || d.K % 4 != 0 || d.K < 32 || !al16(d.A) || !al16(d.B) || d.a_sb % 4 || d.b_sb % 4 || d.a_skb % 4 ||
+        d.b_skb % 4 || d.a_sb2 % 4 || d.b_sb2 % 4 || d.M < 32 || d.N < 32 || (d.K % 32 != 0 && d.kbatch > 1 && d.splitk != 1))
+      return 0;
+    const bool a_kc = d.a_sk == 1 && d.a_sm % 4 == 0, b_kc = d.b_sk == 1 && d.b_sn % 4 == 0;
+    const bool a_ks = d.a_sm == 1 && d.a_sk % 4 == 0 && (d.M % 4 == 0 || d.a_sk >= (d.M + 3) / 4 * 4);
+    const bool b_ks = d.b_sn == 1 && d.b_sk % 4 == 0 && (d.N % 4 == 0 || d.b_sk >= (d.N + 3) / 4 * 4);
+    if (!(a_kc || a_ks) || !(b_kc || b_ks)) return 0;
+    if (!a_kc && b_kc) return 0;  // (k-strided A with k-contiguous B: not on the step's path)
+    if (!a_kc) *rc = launch_f32<true, true>(d, stream);
+    else if (!b_kc) *rc = launch_f32<false, true>(d, stream);
+    else *rc = launch_f32<false, false>(d, stream);
+    return 1;
+  }
   if (d.in_dtype != TMI_BF16) return 0;
   if (!al16(d.A) || !al16(d.B) || d.a_sb % 8 || d.b_sb % 8 || d.a_skb % 8 || d.b_skb % 8) return 0;
   // operand modes: KC = k-contiguous rows (16-byte aligned row starts), KS = k-strided with
