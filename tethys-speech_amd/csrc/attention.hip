@@ -48,11 +48,12 @@ __device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | (
 
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+// Plain fmaxf: hipcc fuses the chain into v_max3_f32 by itself AND pads the MFMA -> VALU hazard in front of it.  Round 4
+// bug fix: until then this was an inline-asm v_max3_f32, and hipcc neither models nor pads an asm statement
+// (cdna_hip_programming.md 5.7 item 2): the first maxima read the score accumulators up to 12 wait states too early - stale
+// registers on some waves of some launches, more of them the busier the CU (3 % of the encoder's attention outputs differed
+// between two identical launches, by up to 20 % of their value; tools/attn_determinism.py).
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float MASKED2 = -1e9f * LOG2E;  // the reference's -1e9, in log2 units
 constexpr float LAZY = 8.f;             // forward: rescale only when a maximum grew by > 2^8
@@ -267,6 +268,7 @@ struct AttnP {
   // ([B*H][ksplit][Tq][64] fp32, then for the forward [B*H][ksplit][Tq][2] = (m, l)) and a combine kernel folds them.
   int ksplit;
   float* part;
+  int dbg;  // TMI_ATTN_DBG (diagnostics)
 };
 
 // ABL (diagnostics, TMI_ATTN_ABL): 1 = no softmax arithmetic (p = s), 2 = no second product, 3 = no staging after the
@@ -419,6 +421,9 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (P.dbg == 1) __builtin_amdgcn_s_sleep(20);
+    if (P.dbg == 2) __syncthreads();
+    if (P.dbg == 3) { __builtin_amdgcn_s_sleep(20); __syncthreads(); }
     if (ABL != 3) cur ^= 1;
   };
   const int nfast = causal ? 0 : min(Tk / TROWS, ntiles);  // full, unmasked tiles first
@@ -834,6 +839,8 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   set_dropout(P);
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
+  static const int adbg = [] { const char* e = getenv("TMI_ATTN_DBG"); return e ? atoi(e) : 0; }();
+  P.dbg = adbg;
   dim3 grid((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int focc = [] { const char* e = getenv("TMI_ATTN_FWD_OCC"); return e ? atoi(e) : 0; }();
@@ -851,7 +858,11 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
     else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 2>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 3) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 3>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 4>), grid, dim3(256), 4 * IMG, hs, P);
-    else hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, hs, P);
+    else {
+      static const int ldsdbg = [] { const char* e = getenv("TMI_ATTN_LDS"); return e ? atoi(e) : 0; }();  // diagnostics: co-residency
+      if (ldsdbg > 4 * IMG) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsdbg);
+      hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), ldsdbg > 4 * IMG ? ldsdbg : 4 * IMG, hs, P);
+    }
   }
   if (P.ksplit > 1) {
     const int64_t rows = dp->B * dp->H * dp->Tq;
