@@ -37,6 +37,12 @@ extern "C" {
 int tmi_abi_version(void);
 /* Last HIP error string seen by a launch in this thread (host pointer, static storage). */
 const char* tmi_last_error(void);
+/* Reproducible reductions, process-wide, read at launch time (returns the previous setting).  On: tmi_colsum runs one
+ * workgroup per column group, so no result depends on the arrival order of fp32 atomics; callers pair it with the
+ * workspace (fixed-order fold) form of tmi_layernorm_bwd.  With both, a Whisper step is bit-reproducible (the reference,
+ * TensorFlow on GPU, is not run-to-run reproducible either: no file:line to cite - this is a property the parity tests
+ * use, tests/test_whisper_step_gpu.py). */
+int tmi_set_deterministic(int on);
 
 /* ------------------------------------------------------------------------------------
  * Strided, batched GEMM with fused epilogue.  Replaces every tf.keras.layers.Dense call

@@ -61,6 +61,7 @@ class AttnDesc(C.Structure):
 SIGNATURES = {
     "tmi_abi_version": (c_i32, []),
     "tmi_last_error": (C.c_char_p, []),
+    "tmi_set_deterministic": (c_i32, [c_i32]),
     "tmi_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "tmi_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
@@ -117,7 +118,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 _lib = None
 
 

@@ -516,7 +516,7 @@ extern "C" int tmi_colsum_batched(const void* dy, int64_t ld, int64_t dy_sb, flo
   int64_t yb = (rows + CS_WAVES * 4 - 1) / (CS_WAVES * 4);  // at least four rows per wave
   const int64_t cap = (cs_blocks + xb * nbatch - 1) / (xb * nbatch);
   if (yb > cap) yb = cap;
-  if (yb < 1) yb = 1;
+  if (yb < 1 || tmi_deterministic()) yb = 1;  // (one workgroup per column group: a single contributor per column, no atomic order)
   dim3 grid((unsigned)xb, (unsigned)yb, (unsigned)nbatch);
   if (dtype == TMI_BF16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(64 * CS_WAVES), 0, s, (const bf16_t*)dy, ld, out, rows, N, dy_sb, out_sb);

@@ -19,5 +19,15 @@ int tmi_check_launch(const char* what) {
   return TMI_OK;
 }
 
-extern "C" int tmi_abi_version(void) { return 21; }
+// Reproducible reductions (tmi_set_deterministic): kernels whose fp32 atomics make a result depend on arrival order take
+// their fixed-order form while it is on (tmi_colsum: one workgroup per column group).  Process-wide, read at launch time.
+static int g_deterministic = 0;
+int tmi_deterministic() { return g_deterministic; }
+extern "C" int tmi_set_deterministic(int on) {
+  const int was = g_deterministic;
+  g_deterministic = on ? 1 : 0;
+  return was;
+}
+
+extern "C" int tmi_abi_version(void) { return 22; }
 extern "C" const char* tmi_last_error(void) { return g_err; }

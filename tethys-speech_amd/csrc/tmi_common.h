@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // thread-local error slot, filled by launch helpers (host side)
 void tmi_set_error(const char* msg);
 int tmi_check_launch(const char* what);
+int tmi_deterministic();  // runtime.hip: tmi_set_deterministic
 
 template <typename T> struct tmi_type;
 template <> struct tmi_type<float> { static constexpr int id = TMI_F32; };

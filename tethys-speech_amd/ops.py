@@ -185,6 +185,17 @@ _LN_WS = {}
 LN_ATOMIC = os.environ.get("TMI_LN_DETERMINISTIC", "0") == "0"
 
 
+def set_deterministic(on: bool) -> bool:
+    """Reproducible reductions for the whole step (returns the previous setting): LayerNorm backward through its workspace +
+    fixed-order fold, column sums with one workgroup per column group (tmi_set_deterministic).  Every other kernel of the
+    Whisper step is order-independent already, so two runs of the same steps then agree bit for bit; costs ~0.1 ms/step."""
+    global LN_ATOMIC
+    was = not LN_ATOMIC
+    LN_ATOMIC = not on
+    lib().tmi_set_deterministic(1 if on else 0)
+    return was
+
+
 def ln_bwd_workspace(device, rows, C, emit):
     """Partial-sum table of tmi_layernorm_bwd (one row of 2-3 * C floats per workgroup): one per (device, stream) like the
     GEMM workspace - the fold launch that reads it follows on the same stream.  An outgrown buffer is parked, never
