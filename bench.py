@@ -307,7 +307,7 @@ def measure_roofline(model, one_step, nprof, precision, tag):
     # same command (tools/pmc_traffic.py), bytes per tmi_gemm launch.  FETCH_SIZE / WRITE_SIZE are the L2's fabric-side
     # counters (Infinity-Cache hits included, guide section HBM), FETCH_SIZE doubled per the gfx950 note.
     traffic, traffic_src = None, None
-    for name in (f"r03_{tag}_gemm_pmc_traffic.json", f"r02_{tag}_gemm_pmc_traffic.json",
+    for name in (f"r04_{tag}_gemm_pmc_traffic.json", f"r03_{tag}_gemm_pmc_traffic.json", f"r02_{tag}_gemm_pmc_traffic.json",
                  f"r01_{tag}_gemm_pmc_traffic.json" if tag != "whisper" else "r01_gemm_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
