@@ -21,6 +21,7 @@
 #include "tmi_common.h"
 #include "gemm_epilogue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -59,6 +60,7 @@ struct FastParams {
   int64_t split_c_stride;  // != 0: split s stores (no atomics) to C + s * split_c_stride (workspace slabs)
   int slots;               // persistent eight-phase kernel: tile slots (8 * ptm * ptn, padding included) dealt over gridDim.x workgroups
   int epi;                 // epilogue class of the lean interior path (EPI_*, epi_class()); 0 = the generic code only
+  int xsplit;              // eight-phase kernel, split-K through slabs: the splits are dealt over XCD GROUPS (see launch_p8); 0 = blockIdx.y
 };
 
 // What an interior 32x64 piece has to do besides bias (+ q scale), decided once per launch on the host.  The generic
@@ -986,8 +988,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][A^0 A^1 B^0 B^1][16 KiB] (+ 32 KiB of epilogue staging, PERSIST)
   const tmi_gemm_desc& d = P.d;
   // tile slot -> tile coordinates (XCD-aware, see gemm_fast_kernel); false for the padding slots of a ragged partition
+  // this workgroup's split when the splits ride on the XCD index (P.xsplit; never with PERSIST): XCDs [s * 8 / S, (s + 1) * 8 / S)
+  // take split s, so their L2s see ONE K range and all of its tiles' panels
+  // (shifts, not divisions: an integer division by a runtime value goes through the vector unit and is no longer provably uniform)
+  const int xsh = P.xsplit == 2 ? 2 : P.xsplit == 4 ? 1 : 0;  // log2 of the XCDs per split
+  const int xsp = P.xsplit ? (int)(blockIdx.x & 7) >> xsh : 0;
   auto decode = [&](int slot, int64_t& m0_, int64_t& n0_) -> bool {
-    const int xcd = slot & 7, lidx = slot >> 3;
+    int xcd = slot & 7;
+    const int lidx = slot >> 3;
+    if (P.xsplit) xcd &= (1 << xsh) - 1;
     int ltm, ltn;
     if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
     else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
@@ -1015,9 +1024,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   // this split's K-tiles [kt0, kt0 + nt)
-  const int nsplit = gridDim.y;
+  const int nsplit = P.xsplit ? P.xsplit : (int)gridDim.y;
   const int per = (P.ktiles + nsplit - 1) / nsplit;
-  const int kt0 = blockIdx.y * per;
+  const int kt0 = (P.xsplit ? xsp : (int)blockIdx.y) * per;
   const int nt = min(P.ktiles, kt0 + per) - kt0;  // may be <= 0 for a trailing split
   // K tail (both operands k-strided, K % 8 == 0; host-checked): rows k >= klast of the last K-tile are
   // fetched from row klast - 1 (in bounds) and the A fragments covering them are zeroed
@@ -1121,7 +1130,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   bf16x8 ar[2][4], b0[4], b1[4];
 
-  auto readA = [&](int bufoff, int a, int t) {
+  // LASTK (compile-time): this K-tile may be the ragged last one of a (KS, KS) launch.  Round 4: the zeroing of the A
+  // fragments beyond K used to sit in every K-tile as 49 predicated selects between the fragment reads and the MFMAs (hipcc
+  // if-converts the uniform test) - the weight gradients' K = 12000 is not a multiple of 64, so they all carried it; now
+  // only the peeled last K-tile does.
+  auto readA = [&](int bufoff, int a, int t, auto lastk_tag) {
+    constexpr bool LASTK = decltype(lastk_tag)::value;
     if constexpr (ABL == 2) return;
     if constexpr (A_KS) {
       const char* img = smem + bufoff + a * P8_HALF;
@@ -1129,7 +1143,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ar[mi][kk] = frag_ks<false>(img, 64 * wr + 32 * mi, kk, lane);
-      if constexpr (B_KS) {
+      if constexpr (B_KS && LASTK) {
         if (tail && kt0 + t == P.ktiles - 1) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
@@ -1174,13 +1188,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 
   // one K-tile = phases 1..4 of the table on buffer OWN_ (phases 5..8 are the same with the buffers swapped).
   // MID_: statement run between phase 2 and phase 3 (the persistent kernel switches its staging offsets to the next tile there)
-#define P8_KTILE(OWN_, T_, MID_)                                              \
+#define P8_KTILE(OWN_, T_, MID_) P8_KTILE_L(OWN_, T_, MID_, std::false_type)
+#define P8_KTILE_L(OWN_, T_, MID_, LASTK_)                                    \
   do {                                                                        \
     const int own = (OWN_), oth = own ^ 1;                                    \
     const int ownoff = own * P8_BUF;                                          \
     readB(ownoff, 0, b0);                                                     \
     __builtin_amdgcn_sched_barrier(0);                                        \
-    readA(ownoff, 0, (T_));                                                   \
+    readA(ownoff, 0, (T_), LASTK_{});                                         \
     stage(oth, 3, (T_) + 1);                                                  \
     p8_barrier();                                                             \
     P8_MMA(0, 0, b0);                                                         \
@@ -1193,7 +1208,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     P8_MMA(0, 1, b1);                                                         \
     p8_barrier();                                                             \
     MID_;                                                                     \
-    readA(ownoff, 1, (T_));                                                   \
+    readA(ownoff, 1, (T_), LASTK_{});                                         \
     stage(own, 2, (T_) + 2);                                                  \
     p8_barrier();                                                             \
     P8_MMA(1, 1, b1);                                                         \
@@ -1289,7 +1304,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
 
     // one K-tile per iteration
     in_loop = true;
-    for (int t = 0; t < nt; ++t) P8_KTILE(t & 1, t, (void)0);
+    if constexpr (A_KS && B_KS) {  // (the only layout with a K tail: its last K-tile is peeled)
+      for (int t = 0; t < nt - 1; ++t) P8_KTILE(t & 1, t, (void)0);
+      P8_KTILE_L((nt - 1) & 1, nt - 1, (void)0, std::true_type);
+    } else {
+      for (int t = 0; t < nt; ++t) P8_KTILE(t & 1, t, (void)0);
+    }
     if (stamping) ts[2] = stamp();
     if (wr == 0) p8_barrier();  // rejoin the other group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages must land before LDS is reused
@@ -1304,10 +1324,15 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   char* E = smem + wave * 8192;
   {
     const int64_t mw0 = m0 + wr * WR, nw0 = n0 + wc * 64;  // (written out: see the persistent form)
-    wide_epilogue<TC, 2>(P, acc[0][0], acc[0][1], E, mw0, nw0, bz, lane, false);
-    wide_epilogue<TC, 2>(P, acc[1][0], acc[1][1], E, mw0 + 32, nw0, bz, lane, false);
-    wide_epilogue<TC, 2>(P, acc[2][0], acc[2][1], E, mw0 + 64, nw0, bz, lane, false);
-    if constexpr (NMI == 4) wide_epilogue<TC, 2>(P, acc[NMI - 1][0], acc[NMI - 1][1], E, mw0 + 96, nw0, bz, lane, false);
+    FastParams Q = P;
+    if (P.xsplit) {  // (the split's slab: the epilogue's own blockIdx.y term is zero in this mapping)
+      Q.d.C = reinterpret_cast<TC*>(d.C) + (int64_t)xsp * P.split_c_stride;
+      Q.split_c_stride = 0;
+    }
+    wide_epilogue<TC, 2>(Q, acc[0][0], acc[0][1], E, mw0, nw0, bz, lane, false);
+    wide_epilogue<TC, 2>(Q, acc[1][0], acc[1][1], E, mw0 + 32, nw0, bz, lane, false);
+    wide_epilogue<TC, 2>(Q, acc[2][0], acc[2][1], E, mw0 + 64, nw0, bz, lane, false);
+    if constexpr (NMI == 4) wide_epilogue<TC, 2>(Q, acc[NMI - 1][0], acc[NMI - 1][1], E, mw0 + 96, nw0, bz, lane, false);
   }
   if (stamping) {
     ts[4] = stamp();
@@ -1318,6 +1343,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   }
   }
 #undef P8_KTILE
+#undef P8_KTILE_L
 #undef P8_MMA
 }
 
@@ -1386,6 +1412,7 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
   P.split_c_stride = 0;
+  P.xsplit = 0;
   P.slots = 0;
   P.drop_thr = tmi_drop_thr(d.dropout_p);
   P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
@@ -1511,6 +1538,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg8 = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg8;
   P.split_c_stride = 0;
+  P.xsplit = 0;
   P.drop_thr = tmi_drop_thr(d.dropout_p);
   P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
   P.drop_scale = tmi_keep_scale(P.drop_thr);
@@ -1574,6 +1602,29 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
         return tmi_check_launch("tmi_gemm(p8 persistent)");
       }
     }
+  }
+  // Split-K over XCD groups (round 4): with the split on blockIdx.y every XCD serves all S K-ranges, each with its own
+  // panels; dealt over groups of 8 / S XCDs instead, an XCD's L2 holds ONE K-range and (tiles / (8 / S)) tiles that share its
+  // row and column panels (fc weight gradient, S = 4: 15 -> 9 panel fetches from beyond L2 per 18 tiles).
+  static const int xsplit_on = [] { const char* e = getenv("TMI_GEMM_XSPLIT"); return e ? atoi(e) : 1; }();
+  if (xsplit_on && d.nbatch == 1 && (splitk == 2 || splitk == 4 || splitk == 8)) {
+    const int groups = 8 / splitk;  // XCDs per split: 4, 2 or 1
+    int bxn = 1;
+    int64_t bpad = -1;
+    for (int cand = 1; cand <= groups; cand *= 2) {
+      const int64_t padded = (int64_t)((P.tiles_m + groups / cand - 1) / (groups / cand)) * ((P.tiles_n + cand - 1) / cand);
+      if (bpad < 0 || padded < bpad) { bpad = padded; bxn = cand; }
+    }
+    P.xsplit = splitk;
+    P.xn = bxn;
+    P.xm = groups / bxn;
+    P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
+    P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+    P.slots = 8 * P.ptm * P.ptn;
+    dim3 gridx((unsigned)(8 * P.ptm * P.ptn), 1u, 1u);
+    return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+      hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), gridx, dim3(512), 2 * P8_BUF, stream, Q);
+    });
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && BM == 192) {  // diagnostics: TMI_GEMM_DBG & 6 = 2 no MFMA / reads, 4 no staging in the loop
@@ -1879,6 +1930,7 @@ int launch_f32(const tmi_gemm_desc& d, hipStream_t stream) {
   static const int dbg = [] { const char* e = getenv("TMI_GEMM_DBG"); return e ? atoi(e) : 0; }();
   P.dbg = dbg;
   P.split_c_stride = 0;
+  P.xsplit = 0;
   P.slots = 0;
   P.drop_thr = tmi_drop_thr(d.dropout_p);
   P.drop_key = tmi_stream_key(d.dropout_seed, 0u);
