@@ -697,7 +697,10 @@ void gemm_fast_kernel(const FastParams P) {
   // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so
   // blockIdx.x % 8 labels the XCD.  The tile grid is cut into xm x xn rectangles, one per XCD,
   // sized so that an XCD's slice of B stays resident in its 4 MiB L2 while A panels stream.
-  const int xcd = blockIdx.x & 7, lidx = blockIdx.x >> 3;
+  // (P.xsplit: split-K dealt over XCD groups instead of blockIdx.y - see launch_p8)
+  const int xsh = P.xsplit == 2 ? 2 : P.xsplit == 4 ? 1 : 0;
+  const int xsp = P.xsplit ? (int)(blockIdx.x & 7) >> xsh : 0;
+  const int xcd = P.xsplit ? (int)(blockIdx.x & 7) & ((1 << xsh) - 1) : (int)(blockIdx.x & 7), lidx = blockIdx.x >> 3;
   int ltm, ltn;
   if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
   else { ltm = lidx / P.ptn; ltn = lidx - ltm * P.ptn; }
@@ -717,9 +720,9 @@ void gemm_fast_kernel(const FastParams P) {
   constexpr int NTHREADS = NW * (K::SPEC ? 128 : 64);
 
   const int total_it = (int)d.kbatch * P.ktiles;
-  const int nsplit = gridDim.y;
+  const int nsplit = P.xsplit ? P.xsplit : (int)gridDim.y;
   const int per = (total_it + nsplit - 1) / nsplit;
-  const int it0 = blockIdx.y * per;
+  const int it0 = (P.xsplit ? xsp : (int)blockIdx.y) * per;
   const int nt = min(total_it, it0 + per) - it0;
 
   const bf16_t* Abase = reinterpret_cast<const bf16_t*>(d.A) + bz * d.a_sb;
@@ -921,9 +924,15 @@ void gemm_fast_kernel(const FastParams P) {
   static_assert(NI == 2, "epilogue pieces are 64 columns wide");
   const bool atomic = nsplit > 1;
   char* E = smem + wave * 8192;
+  FastParams Q = P;
+  if (P.xsplit && P.split_c_stride) {  // (the split's slab; the epilogue's own blockIdx.y term is zero in this mapping)
+    Q.d.C = reinterpret_cast<TC*>(d.C) + (int64_t)xsp * P.split_c_stride;
+    Q.split_c_stride = 0;
+  }
 #pragma unroll
   for (int p = 0; p < MI; ++p)
-    wide_epilogue<TC, (MI * NI * 16 <= 32 ? 2 : 1)>(P, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane, atomic);
+    wide_epilogue<TC, (MI * NI * 16 <= 32 ? 2 : 1)>(Q, acc[p][0], acc[p][1], E, m0 + wr * K::WM + p * 32, n0 + wc * K::WN, bz, lane,
+                                                    atomic && P.split_c_stride == 0);
   }
 }
 
@@ -1502,8 +1511,24 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
     splitk = 1;
     ws_split = false;
   }
+  static const int xsplit_on = [] { const char* e = getenv("TMI_GEMM_XSPLIT"); return e ? atoi(e) : 1; }();
+  if (xsplit_on && d.nbatch == 1 && (splitk == 2 || splitk == 4 || splitk == 8)) {  // split-K over XCD groups: see launch_p8
+    const int groups = 8 / splitk;
+    int bxn = 1;
+    int64_t bpad = -1;
+    for (int cand = 1; cand <= groups; cand *= 2) {
+      const int64_t padded = (int64_t)((P.tiles_m + groups / cand - 1) / (groups / cand)) * ((P.tiles_n + cand - 1) / cand);
+      if (bpad < 0 || padded < bpad) { bpad = padded; bxn = cand; }
+    }
+    P.xsplit = splitk;
+    P.xn = bxn;
+    P.xm = groups / bxn;
+    P.ptm = (P.tiles_m + P.xm - 1) / P.xm;
+    P.ptn = (P.tiles_n + P.xn - 1) / P.xn;
+    splitk = 1;  // (grid.y)
+  }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
-  if (ws_split) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+  if (ws_split) return launch_with_slabs(P, P.xsplit ? P.xsplit : splitk, stream, [&](const FastParams& Q) {
     hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64) * kKG<CFG>), LDS_BYTES, stream, Q);
   });
   hipLaunchKernelGGL(kern, grid, dim3(NW * (K::SPEC ? 128 : 64) * kKG<CFG>), LDS_BYTES, stream, P);
