@@ -116,43 +116,61 @@ def gemm_workspace(device):
     return ws
 
 
+_GEMM_DESCS = {}   # call-site key -> (descriptor, byref): a step repeats the same ~150 launches with the same pointers and shapes
+
+
 def gemm(A, B, Cm, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, *, nbatch=1, a_sb=0, b_sb=0, c_sb=0,
          kbatch=1, a_skb=0, b_skb=0, bias=None, bias_sb=0, scale_cols=0, scale=1.0, accumulate=False,
          act=0, aux_out=None, aux_in=None, resid=None, r_ld=0, r_sb=0, splitk=1,
          a_off=0, b_off=0, c_off=0, dropout_p=0.0, dropout_seed=0, nbatch2=1, a_sb2=0, b_sb2=0, c_sb2=0):
     """C = epi(A·B); see tmi_gemm in include/tethys_mi.h.  ``*_off`` are element offsets
-    added to the tensors' base pointers (aux_* share c_off).  ``nbatch2`` / ``*_sb2``: an outer batch level."""
-    d = GemmDesc()
-    esA, esC = A.element_size(), Cm.element_size()
-    d.A = A.data_ptr() + a_off * esA
-    d.B = B.data_ptr() + b_off * B.element_size()
-    d.C = Cm.data_ptr() + c_off * esC
-    d.M, d.N, d.K = M, N, K
-    d.a_sm, d.a_sk, d.b_sk, d.b_sn, d.ldc = a_sm, a_sk, b_sk, b_sn, ldc
-    d.nbatch, d.a_sb, d.b_sb, d.c_sb = nbatch, a_sb, b_sb, c_sb
-    d.kbatch, d.a_skb, d.b_skb = kbatch, a_skb, b_skb
-    d.bias = ptr(bias)
-    d.bias_sb = bias_sb
-    d.scale_cols, d.scale = scale_cols, scale
-    d.accumulate = 1 if accumulate else 0
-    d.act = act
-    d.aux_out = None if aux_out is None else aux_out.data_ptr() + c_off * esC
-    d.aux_in = None if aux_in is None else aux_in.data_ptr() + c_off * esC
-    d.resid = ptr(resid)
-    d.r_ld, d.r_sb = r_ld, r_sb
-    d.splitk = splitk
-    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
-    d.nbatch2, d.a_sb2, d.b_sb2, d.c_sb2 = nbatch2, a_sb2, b_sb2, c_sb2
-    if splitk == 0 and Cm.is_cuda:
-        ws = gemm_workspace(Cm.device)
-        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    assert A.dtype == B.dtype
-    d.in_dtype, d.out_dtype = dt(A), dt(Cm)
+    added to the tensors' base pointers (aux_* share c_off).  ``nbatch2`` / ``*_sb2``: an outer batch level.
+    The descriptor is a pure function of the arguments (only the dropout seed changes from step to step), so it is built
+    once per distinct call and reused: filling 45 ctypes fields cost more host time than the launch itself (round 4)."""
+    ws = gemm_workspace(Cm.device) if (splitk == 0 and Cm.is_cuda) else None
+    key = (A.data_ptr(), B.data_ptr(), Cm.data_ptr(), M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, nbatch, a_sb, b_sb, c_sb, kbatch, a_skb,
+           b_skb, None if bias is None else bias.data_ptr(), bias_sb, scale_cols, scale, accumulate, act,
+           None if aux_out is None else aux_out.data_ptr(), None if aux_in is None else aux_in.data_ptr(),
+           None if resid is None else resid.data_ptr(), r_ld, r_sb, splitk, a_off, b_off, c_off, dropout_p, nbatch2, a_sb2, b_sb2,
+           c_sb2, A.dtype, B.dtype, Cm.dtype, None if ws is None else ws.data_ptr())
+    hit = _GEMM_DESCS.get(key)
+    if hit is None:
+        d = GemmDesc()
+        esA, esC = A.element_size(), Cm.element_size()
+        d.A = A.data_ptr() + a_off * esA
+        d.B = B.data_ptr() + b_off * B.element_size()
+        d.C = Cm.data_ptr() + c_off * esC
+        d.M, d.N, d.K = M, N, K
+        d.a_sm, d.a_sk, d.b_sk, d.b_sn, d.ldc = a_sm, a_sk, b_sk, b_sn, ldc
+        d.nbatch, d.a_sb, d.b_sb, d.c_sb = nbatch, a_sb, b_sb, c_sb
+        d.kbatch, d.a_skb, d.b_skb = kbatch, a_skb, b_skb
+        d.bias = ptr(bias)
+        d.bias_sb = bias_sb
+        d.scale_cols, d.scale = scale_cols, scale
+        d.accumulate = 1 if accumulate else 0
+        d.act = act
+        d.aux_out = None if aux_out is None else aux_out.data_ptr() + c_off * esC
+        d.aux_in = None if aux_in is None else aux_in.data_ptr() + c_off * esC
+        d.resid = ptr(resid)
+        d.r_ld, d.r_sb = r_ld, r_sb
+        d.splitk = splitk
+        d.dropout_p = dropout_p
+        d.nbatch2, d.a_sb2, d.b_sb2, d.c_sb2 = nbatch2, a_sb2, b_sb2, c_sb2
+        if ws is not None:
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        assert A.dtype == B.dtype
+        d.in_dtype, d.out_dtype = dt(A), dt(Cm)
+        if len(_GEMM_DESCS) > 8192:   # (ragged batches / many models in one process: start over rather than grow without bound)
+            _GEMM_DESCS.clear()
+        hit = _GEMM_DESCS[key] = (d, C.byref(d))
+    d, ref = hit
+    if dropout_p > 0.0:
+        d.dropout_seed = dropout_seed
     if PROFILE is None:
-        check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
+        check(lib().tmi_gemm(ref, stream()), "tmi_gemm")
         return
     with _probe("gemm", 2.0 * M * N * K * max(1, nbatch) * max(1, kbatch) * max(1, nbatch2)):
-        check(lib().tmi_gemm(C.byref(d), stream()), "tmi_gemm")
+        check(lib().tmi_gemm(ref, stream()), "tmi_gemm")
 
 
 def linear(x2d, w, out, *, w_is_kn=True, **kw):
