@@ -279,6 +279,39 @@ def test_gemm_lean_epilogue_classes_and_persistent_tiles(dev, cls, M, N, K, b_kn
         assert rel_err(aux, acc + bias.double()) <= 1.5e-2
 
 
+@pytest.mark.parametrize("R,d,Vp", [(800, 768, 51904), (520, 512, 16448), (520, 256, 66048)])
+def test_gemm_lm_head_shapes(dev, R, d, Vp):
+    """Round 4: the LM head's three launches as whisper.py issues them (W:545, W:579-600).  Forward [R, Vp] from K = d - the
+    eight-phase kernel's persistent form on 256-row tiles although R < 2048 (more than 512 tiles); weight gradient
+    [d, Vp] from K = R (short reduction, > 512 tiles: eight-phase, no split); dgrad [R, d] from K = Vp into fp32 - a
+    handful of tiles under a very deep reduction: 16 / 32 slab splits dealt 2 / 4 per XCD (gemm_fast.hip launch_p8,
+    xsplit >= 16).  The other two shapes reach the 8-split and the 32-split forms of the same dgrad rule.  Row- and
+    column-wise errors: a skipped tile or a K range added twice / never shows in ITS rows."""
+    ops = _ops()
+    bf = torch.bfloat16
+    x = rnd((R, d), bf, dev, 31)
+    W = rnd((d, Vp), bf, dev, 32, 0.05)
+    dlog = rnd((R, Vp), bf, dev, 33, 0.02)
+    logits = torch.empty((R, Vp), dtype=bf, device=dev)
+    dW = torch.empty((d, Vp), dtype=torch.float32, device=dev)
+    dx = torch.zeros((R, d), dtype=torch.float32, device=dev)
+
+    def check(got, ref, tol):
+        err_r = ((got.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-9)).max().item()
+        err_c = ((got.double() - ref).norm(dim=0) / ref.norm(dim=0).clamp_min(1e-9)).max().item()
+        assert err_r <= tol and err_c <= tol, (err_r, err_c)
+
+    ops.gemm(x, W, logits, R, Vp, d, d, 1, Vp, 1, Vp)
+    check(logits, x.double() @ W.double(), 1e-2)               # bf16 output rounding
+    ops.gemm(x, dlog, dW, d, Vp, R, 1, d, Vp, 1, Vp, splitk=0)
+    check(dW, x.double().t() @ dlog.double(), 1e-5)            # fp32 accumulation of exact bf16 products
+    ops.gemm(dlog, W, dx, R, d, Vp, Vp, 1, 1, Vp, d, splitk=0)
+    check(dx, dlog.double() @ W.double().t(), 1e-5)
+    again = torch.zeros_like(dx)
+    ops.gemm(dlog, W, again, R, d, Vp, Vp, 1, 1, Vp, d, splitk=0)
+    assert torch.equal(again, dx)  # (slab splits, reduced in a fixed order: bit-reproducible)
+
+
 @pytest.mark.parametrize("T,Kin,N", [(4128, 768, 2304), (4640, 1544, 1160), (4128, 256, 768), (8200, 128, 384)])
 def test_gemm_weight_gradient_paths(dev, T, Kin, N):
     """dW[Kin, N] = X^T dY over T tokens (T % 64 = 32 or 8: K tail), library-chosen split-K with the

@@ -1000,11 +1000,14 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
   // this workgroup's split when the splits ride on the XCD index (P.xsplit; never with PERSIST): XCDs [s * 8 / S, (s + 1) * 8 / S)
   // take split s, so their L2s see ONE K range and all of its tiles' panels
   // (shifts, not divisions: an integer division by a runtime value goes through the vector unit and is no longer provably uniform)
+  // S = 16 / 32 (deep reductions onto few tiles - the LM head's dgrad, K = 51904 onto 800 x 768): 2 / 4 K ranges per XCD, taken
+  // by alternate workgroups of the XCD, every range with ALL the tiles - each operand byte enters exactly one L2, once
   const int xsh = P.xsplit == 2 ? 2 : P.xsplit == 4 ? 1 : 0;  // log2 of the XCDs per split
-  const int xsp = P.xsplit ? (int)(blockIdx.x & 7) >> xsh : 0;
+  const int xss = P.xsplit == 16 ? 1 : P.xsplit == 32 ? 2 : 0;  // log2 of the splits per XCD
+  const int xsp = P.xsplit ? (((int)(blockIdx.x & 7) >> xsh) << xss) | ((int)(blockIdx.x >> 3) & ((1 << xss) - 1)) : 0;
   auto decode = [&](int slot, int64_t& m0_, int64_t& n0_) -> bool {
     int xcd = slot & 7;
-    const int lidx = slot >> 3;
+    const int lidx = (slot >> 3) >> xss;
     if (P.xsplit) xcd &= (1 << xsh) - 1;
     int ltm, ltn;
     if (P.walk_m) { ltn = lidx / P.ptm; ltm = lidx - ltn * P.ptm; }
@@ -1608,6 +1611,15 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
       int64_t want = 256 / wgs;
       if (want > P.ktiles / 6) want = P.ktiles / 6;
       if (want > cap) want = cap;
+      // (round 4) a very deep reduction onto a handful of tiles (>= 32 K-tiles per split left): as many splits as fill the
+      // chip, a power of two so that they can be dealt over the XCDs (below)
+      static const int deep = [] { const char* e = getenv("TMI_GEMM_P8_DEEPSPLIT"); return e ? atoi(e) : 32; }();
+      const int64_t tiles = (int64_t)P.tiles_m * P.tiles_n;
+      if (d.nbatch == 1 && deep > cap && tiles <= 32) {
+        int64_t w2 = 1;
+        while (w2 * 2 <= deep && w2 * 2 * tiles <= 256 && P.ktiles / (w2 * 2) >= 32) w2 *= 2;
+        if (w2 > want) want = w2;
+      }
       if (want > d.workspace_bytes / slab_bytes) want = d.workspace_bytes / slab_bytes;
       if (want > 1) splitk = (int)want;
     }
@@ -1632,6 +1644,17 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
   // panels; dealt over groups of 8 / S XCDs instead, an XCD's L2 holds ONE K-range and (tiles / (8 / S)) tiles that share its
   // row and column panels (fc weight gradient, S = 4: 15 -> 9 panel fetches from beyond L2 per 18 tiles).
   static const int xsplit_on = [] { const char* e = getenv("TMI_GEMM_XSPLIT"); return e ? atoi(e) : 1; }();
+  if (xsplit_on && d.nbatch == 1 && (splitk == 16 || splitk == 32)) {  // splitk / 8 K ranges per XCD, each with all the tiles
+    P.xsplit = splitk;
+    P.xn = P.xm = 1;
+    P.ptm = P.tiles_m;
+    P.ptn = P.tiles_n;
+    P.slots = 8 * P.ptm * P.ptn * (splitk / 8);
+    dim3 gridx((unsigned)P.slots, 1u, 1u);
+    return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
+      hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), gridx, dim3(512), 2 * P8_BUF, stream, Q);
+    });
+  }
   if (xsplit_on && d.nbatch == 1 && (splitk == 2 || splitk == 4 || splitk == 8)) {
     const int groups = 8 / splitk;  // XCDs per split: 4, 2 or 1
     int bxn = 1;
@@ -1720,12 +1743,28 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     }
     return launch_cfg<TC, A_KS, B_KS, 6>(d, stream);
   }
+  // fp32 results of a very deep reduction onto few tiles (the LM head's dgrad: [800, 768] from K = 51904, 134 us on the 128x128
+  // kernel with 8 atomic splits): eight-phase kernel, 16 / 32 slab splits dealt two / four per XCD (launch_p8)
+  if constexpr (!A_KS && sizeof(TC) == 4) {
+    static const int deep_on = [] { const char* e = getenv("TMI_GEMM_P8_DEEP"); return e ? atoi(e) : 1; }();
+    const int64_t t192 = ((d.M + 191) / 192) * ((d.N + 255) / 256), t256 = ((d.M + 255) / 256) * ((d.N + 255) / 256);
+    if (deep_on && force < 0 && wgrad_like && d.workspace && p8_eligible(d, false, B_KS) && d.nbatch == 1 && d.K >= 16384 &&
+        d.M >= 512 && d.N >= 256 && t256 <= 32 && 16 * d.M * d.N * 4 <= d.workspace_bytes) {
+      if (t192 <= 32 && (d.M + 191) / 192 * 192 < (d.M + 255) / 256 * 256) return launch_p8<TC, false, B_KS, 192>(d, stream);
+      return launch_p8<TC, false, B_KS>(d, stream);
+    }
+  }
   // weight gradients with a large output and a long reduction: eight-phase kernel, split-K through
   // workspace slabs (-13 % against the 128x128 kernel with atomics; smaller outputs lose)
   if constexpr (A_KS && B_KS && sizeof(TC) == 4) {
     static const int no_p8w = [] { const char* e = getenv("TMI_GEMM_NO_P8"); return e ? atoi(e) : 0; }();
+    // (round 4: the LM head's weight gradient - [768, 51904] from K = 800, 609 tiles - 140 -> 110 us: with two and a half
+    // rounds of tiles the short reduction's prologue and epilogue overlap other tiles' loops)
+    static const int wide_on = [] { const char* e = getenv("TMI_GEMM_P8_WIDE"); return e ? atoi(e) : 1; }();
+    const bool wide_out = wide_on && big_tiles >= 512;
     if (!no_p8w && force < 0 && wgrad_like && d.workspace && p8_eligible(d, true, true) && d.M * d.N >= 768 * 2304 &&
-        d.K >= 4096 && d.nbatch == 1 && (2 * d.M * d.N * 4 <= d.workspace_bytes || big_tiles >= 192))  // (>= 192 tiles: no split, no slabs)
+        (d.K >= 4096 || (wide_out && d.K >= 512)) && d.nbatch == 1 &&
+        (2 * d.M * d.N * 4 <= d.workspace_bytes || big_tiles >= 192))  // (>= 192 tiles: no split, no slabs)
       return launch_p8<TC, true, true>(d, stream);
   }
   // Eight-phase 256x256 kernel (measured, tools/gemm_p8_check.py, tools/gemm_rule_probe.py): +20 % on long
@@ -1738,8 +1777,11 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     // (round 4: batched launches count their batches - the conv2 forward is 8 x [1500, 768] x K 2304 and ran 148 us on the
     // 2-stage 256x256 kernel)
     static const int p8_all = [] { const char* e = getenv("TMI_GEMM_P8_ALL"); return e ? atoi(e) : 0; }();  // (off: level or +0.04 ms in the step, profiles/r04_step_ab_p8_all.txt)
-    const bool m_ok = d.M >= 2048 || (p8_all && d.M >= 1024 && d.M * d.nbatch >= 4096);
+    // (round 4: the LM head's forward, [800, 51904] from K = 768 - 812 tiles walked by the persistent form: 127 -> 111 us)
+    static const int wide_on = [] { const char* e = getenv("TMI_GEMM_P8_WIDE"); return e ? atoi(e) : 1; }();
+    const bool m_ok = d.M >= 2048 || (p8_all && d.M >= 1024 && d.M * d.nbatch >= 4096) || (wide_on && d.M >= 512 && big_tiles >= 512);
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && m_ok && d.N >= 256) {
+      if (d.M < 1024) return launch_p8<TC, false, B_KS>(d, stream);  // (the LM head's forward: 256-row tiles measured ahead of 192)
       // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
       static const int no192 = [] { const char* e = getenv("TMI_GEMM_NO_P8_192"); return e ? atoi(e) : 0; }();
       // (round 4: on by default - with the lean epilogue the 192-row tile beats the two co-resident 128x128 workgroups in the step

@@ -133,13 +133,17 @@ __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64
   }
 }
 
-// bf16 rows short enough to be held in registers (ld <= 256 * 8 * XR elements: the 51904-column Whisper logits are 26
-// 16-byte chunks per thread): ONE read of the row, base-2 exponentials (v_exp_f32; the output is bf16), one write.  The
-// generic kernel above reads the row twice and spends most of its time in expf (two calls per element).
-constexpr int XR = 28;
-__global__ __launch_bounds__(256) void xent_rows_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
-                                                             float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
+// bf16 rows short enough to be held on chip (ld <= 256 * 8 * XR elements: the 51904-column Whisper logits are 26 16-byte
+// chunks per thread): ONE read of the row, base-2 exponentials (v_exp_f32; the output is bf16), one write.  The generic
+// kernel above reads the row twice and spends most of its time in expf (two calls per element).
+// Round 4: the row's chunks are split between registers (XREG per thread) and LDS (XLDS per thread, 36 KiB per workgroup).
+// With all 26-28 chunks in registers the kernel needed 156 VGPRs = 3 workgroups per CU = 768 resident rows, and the step's
+// 800 rows ran as a full round plus a 32-row tail (64 us); at <= 128 VGPRs and 36 KiB four workgroups fit: one round.
+constexpr int XREG = 17, XLDS = 9, XR = XREG + XLDS;
+__global__ __launch_bounds__(256, 4) void xent_rows_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
+                                                                float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
   __shared__ float red[4];
+  __shared__ u32x4 spill[XLDS * 256];  // chunk XREG + k of thread t at spill[k * 256 + t]
   const int64_t row = blockIdx.x;
   const int b = (int)(row / S), t = (int)(row % S);
   bf16_t* lr = logits + row * ld;
@@ -152,48 +156,83 @@ __global__ __launch_bounds__(256) void xent_rows_bf16_kernel(bf16_t* __restrict_
   }
   const int target = labels[(int64_t)b * S + t + 1];
   constexpr float L2E = 1.44269504088896340736f;
-  u32x4 raw[XR];
+  u32x4 raw[XREG];
   float mx = -INFINITY;
   const int Vi = (int)V;
-  // (columns >= V of the last chunk are padding: they are turned into -inf once, here, so that the passes below are branch-free)
+  // Loads first, unconditionally (a chunk past the row is fetched from the row's last chunk), then the padding columns
+  // (>= V: the tail of one chunk and the chunks after it) are turned into -inf so that the passes below are branch-free.
+  // The test is per chunk SLOT and wave-uniform - only the slots whose 256 chunks can reach V enter it - so no branch
+  // sits between a load and the next (data-dependent tests there issued the row's 26 loads one at a time).
+  auto load = [&](int ch) -> u32x4 { return reinterpret_cast<const u32x4*>(lr)[ch < nch ? ch : nch - 1]; };
+  auto patch = [&](u32x4& r, int slot, int ch) {
+    if ((slot * 256 + 256) * 8 > Vi) {
+      const int nv = Vi - ch * 8;  // valid columns of this chunk (<= 0: none)
 #pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    const int ch = j * 256 + (int)threadIdx.x;
-    raw[j] = u32x4{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};  // bf16 -inf pairs
-    if (ch < nch) {
-      raw[j] = reinterpret_cast<const u32x4*>(lr)[ch];
-      if (ch * 8 + 8 > Vi) {
-        bf16_t* e = reinterpret_cast<bf16_t*>(&raw[j]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (ch * 8 + i >= Vi) e[i] = (bf16_t)(-INFINITY);
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t keep = (2 * d < nv ? 0xffffu : 0u) | (2 * d + 1 < nv ? 0xffff0000u : 0u);
+        r[d] = (r[d] & keep) | (0xff80ff80u & ~keep);  // bf16 -inf = 0xff80
       }
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
-      float m8 = (float)e[0];
+    }
+  };
+  auto max8 = [](const u32x4& r) -> float {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&r);
+    float m8 = (float)e[0];
 #pragma unroll
-      for (int i = 1; i < 8; ++i) m8 = fmaxf(m8, (float)e[i]);
-      mx = fmaxf(mx, m8);
+    for (int i = 1; i < 8; ++i) m8 = fmaxf(m8, (float)e[i]);
+    return m8;
+  };
+  {  // (the LDS-bound chunks first and fenced off: hoisted above them, the XREG register loads would keep all 26 chunks live at once)
+    u32x4 tmp[XLDS];
+#pragma unroll
+    for (int k = 0; k < XLDS; ++k) tmp[k] = load((XREG + k) * 256 + (int)threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < XLDS; ++k) {
+      patch(tmp[k], XREG + k, (XREG + k) * 256 + (int)threadIdx.x);
+      spill[k * 256 + threadIdx.x] = tmp[k];  // (read back by the same thread only: no barrier needed)
+      mx = fmaxf(mx, max8(tmp[k]));
     }
   }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < XREG; ++j) raw[j] = load(j * 256 + (int)threadIdx.x);
+#pragma unroll
+  for (int j = 0; j < XREG; ++j) {
+    patch(raw[j], j, j * 256 + (int)threadIdx.x);
+    mx = fmaxf(mx, max8(raw[j]));
+  }
+  // (opaque between the passes: otherwise the bf16 -> fp32 unpacking is shared across them and 17 x 8 floats stay live)
+  auto pin = [&]() {
+#pragma unroll
+    for (int j = 0; j < XREG; ++j) asm volatile("" : "+v"(raw[j]));
+  };
+  pin();
   const float gmx = block_max_256(mx, red);
   const float nb = -gmx * L2E;
   float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
+  auto sum8 = [&](const u32x4& r) {
+    const bf16_t* e = reinterpret_cast<const bf16_t*>(&r);
 #pragma unroll
     for (int i = 0; i < 8; ++i) sum += __builtin_amdgcn_exp2f(fmaf((float)e[i], L2E, nb));  // exp2(-inf) = 0 for the padding
+  };
+#pragma unroll
+  for (int j = 0; j < XREG; ++j) {
+    sum8(raw[j]);
+    __builtin_amdgcn_sched_barrier(0);
   }
+#pragma unroll
+  for (int k = 0; k < XLDS; ++k) {
+    if (k % 3 == 0) __builtin_amdgcn_sched_barrier(0);  // (three LDS reads in flight, not nine held beside raw[])
+    sum8(spill[k * 256 + threadIdx.x]);
+  }
+  pin();
   const float gsum = block_sum_256(sum, red);
   const float inv = grad_scale / gsum;
   if (threadIdx.x == 0) row_loss[row] = gmx + logf(gsum) - (float)lr[target];
   __syncthreads();  // the target logit is read before anyone overwrites it
   const int tch = target >> 3, ti = target & 7;
-#pragma unroll
-  for (int j = 0; j < XR; ++j) {
-    const int ch = j * 256 + (int)threadIdx.x;
+  auto emit = [&](int ch, const u32x4& r) {
     if (ch < nch) {
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&raw[j]);
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&r);
       float g[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] = __builtin_amdgcn_exp2f(fmaf((float)e[i], L2E, nb)) * inv;
@@ -207,6 +246,16 @@ __global__ __launch_bounds__(256) void xent_rows_bf16_kernel(bf16_t* __restrict_
       for (int i = 0; i < 8; ++i) o[i] = (bf16_t)g[i];
       *reinterpret_cast<bf16x8*>(lr + (int64_t)ch * 8) = o;
     }
+  };
+#pragma unroll
+  for (int j = 0; j < XREG; ++j) {
+    emit(j * 256 + (int)threadIdx.x, raw[j]);
+    __builtin_amdgcn_sched_barrier(0);  // (chunk by chunk: interleaved, the scheduler keeps several chunks' fp32 values live)
+  }
+#pragma unroll
+  for (int k = 0; k < XLDS; ++k) {
+    __builtin_amdgcn_sched_barrier(0);
+    emit((XREG + k) * 256 + (int)threadIdx.x, spill[k * 256 + threadIdx.x]);
   }
 }
 
