@@ -242,6 +242,15 @@ int tmi_embed_bwd(const int32_t* labels, const void* dy, float* dtable, int64_t 
  */
 int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss,
                      int64_t B, int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream);
+/* The same cross-entropy for logits that are the output of an LM head (W:579-600: logits = decoder_out . lm_head): x[B*S, d]
+ * (row stride x_ld) and w (element (k, n) at w[k*w_sk + n*w_sn]) are the operands tmi_gemm produced `logits` from.  bf16
+ * logits have lost the low bits of the target logit (ulp 0.03 at |z| in [4, 8)) and the loss is lse - z_target, so the row's
+ * workgroup recomputes z_target = x[row, :] . w[:, target] in fp32 for row_loss; lse and the gradient come from `logits` as
+ * in tmi_xent_fwd_bwd.  On the headline golden this takes the bf16 loss-curve error from 7.7e-4 to 2.0e-4
+ * (profiles/r04_bf16_margin.txt).  fp32 logits: identical to tmi_xent_fwd_bwd (x, w are validated and ignored). */
+int tmi_linear_xent(const void* x, int64_t x_ld, const void* w, int64_t w_sk, int64_t w_sn, int64_t d, void* logits, int64_t ld,
+                    const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V, float grad_scale, int32_t dtype,
+                    void* stream);
 int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -740,6 +740,46 @@ def test_xent(dev, dtype, V, ld):
     assert float(logits[:, V:].abs().max()) == 0.0 if ld > V else True
 
 
+@pytest.mark.parametrize("R_S,d,V,ld", [((3, 10), 96, 1003, 1024), ((2, 7), 768, 51865, 51904), ((2, 5), 64, 60001, 60008)])
+def test_linear_xent_takes_the_target_logit_from_the_operands(dev, R_S, d, V, ld):
+    """tmi_linear_xent (round 4): cross-entropy of bf16 logits = x . w whose LOSS uses z_target recomputed in fp32 from x and w
+    (the bf16 logits have lost its low bits); lse and the gradient come from the stored logits exactly as in tmi_xent_fwd_bwd.
+    Checked against that definition in fp64, for the on-chip-row kernel and the generic one (60001 columns), with logits large
+    enough (|z| up to ~8) for the rounding to matter; the gradient must be bit-identical to the plain entry's; and the loss
+    must be closer to the cross-entropy of the unrounded logits than the plain one is."""
+    ops = _ops()
+    B, S = R_S
+    bf = torch.bfloat16
+    x = rnd((B * S, d), bf, dev, 91, 1.0)
+    w = torch.zeros((d, ld), dtype=bf, device=dev)
+    w[:, :V] = rnd((d, V), bf, dev, 92, 2.0 / math.sqrt(d))
+    _, labels = O.create_dummy_pool(seed=4, n_mels=4, seq_len=8, max_target_length=S, num_samples=B)
+    lab = torch.from_numpy(labels).to(dev)
+    logits = torch.empty((B * S, ld), dtype=bf, device=dev)
+    ops.gemm(x, w, logits, B * S, ld, d, d, 1, ld, 1, ld)
+    stored = logits.clone()
+    plain = stored.clone()
+    gs = 1.0 / (B * (S - 1))
+    rl_plain = torch.empty(B * S, dtype=torch.float32, device=dev)
+    rl = torch.empty_like(rl_plain)
+    ops.xent_fwd_bwd(plain, ld, lab, rl_plain, B, S, V, gs)
+    ops.xent_fwd_bwd(logits, ld, lab, rl, B, S, V, gs, lm=(x, d, w, ld, 1, d))
+    torch.cuda.synchronize()
+    assert torch.equal(logits, plain)                      # same gradient, bit for bit
+    z = stored.double()[:, :V].view(B, S, V)               # what the kernel sees
+    z_exact = (x.double() @ w.double())[:, :V].view(B, S, V)
+    tgt = lab[:, 1:].long()
+    lse = torch.logsumexp(z[:, :-1], dim=-1)
+    want = lse - z_exact[:, :-1].gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    got = rl.view(B, S)
+    assert float(got[:, -1].abs().max()) == 0.0
+    assert float((got[:, :-1].double() - want).abs().max()) <= 5e-5
+    full = torch.logsumexp(z_exact[:, :-1], dim=-1) - z_exact[:, :-1].gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    err_new = float((got[:, :-1].double() - full).abs().mean())
+    err_old = float((rl_plain.view(B, S)[:, :-1].double() - full).abs().mean())
+    assert err_new < 0.5 * err_old, (err_new, err_old)
+
+
 @pytest.mark.parametrize("eps_mode", [0, 1])
 def test_adam(dev, eps_mode):
     ops = _ops()

@@ -191,13 +191,14 @@ def test_whisper_tiny_loss_curve_golden(dev, precision, tol):
     within(f"whisper-tiny B=2 10-step golden {precision} max |dloss|", err, tol, (got, gold["losses"]))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-3)])  # measured 1.2e-6 / 8.4e-4: both held to the north star's 1e-3
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 1e-3)])  # measured 1.2e-6 / 2.6e-4: both held to the north star's 1e-3
 def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     """BASELINE.json's headline model at its headline batch (configs[1]): Whisper small-ref (768/12h/3072/4+4,
     W:13-18), per-GPU batch 8, 30 s clips, Adam 1e-4 (W:901), dropout 0, the bench.py pool (seed 1234), 10 steps
     against the committed fp64-oracle curve.  This is the north-star's "loss curve matching to 1e-3" on the model
     it names, held by BOTH paths: fp32 (the parity mode, ~1e-6 measured) and bf16 (the perf mode the bench times,
-    8.4e-4 measured: a breach of the 1e-3 contract fails here rather than hiding under a looser bound).  ``dataset.batch(8).repeat()`` keeps the remainder (W:812-815): step 6 is the
+    2.6e-4 measured since tmi_linear_xent reads the loss's target logit in fp32 - 7.7e-4 before, all of the difference the
+    bf16 rounding of that one logit per row: a breach of the 1e-3 contract fails here rather than hiding under a looser bound).  ``dataset.batch(8).repeat()`` keeps the remainder (W:812-815): step 6 is the
     two-sample batch."""
     path = os.path.join(GOLD, "whisper_small_ref_b8_10steps.json")
     if not os.path.exists(path):
@@ -246,6 +247,8 @@ def test_whisper_small_ref_b8_loss_curve_golden(dev, precision, tol):
     within(f"whisper small-ref B=8 10-step golden {precision} max |dloss|", max(err), tol, (err, got, gold["losses"]))
     if precision == "fp32":  # the north star's 1e-3 is the contract; what the fp32 path actually holds is ~1e-6
         assert max(err) <= 1e-5, err
+    else:  # (<= 6e-4 with the contract's bound left at 1e-3; 2.6e-4 measured, reproducible)
+        assert max(err) <= 6e-4, err
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -79,6 +79,7 @@ SIGNATURES = {
     "tmi_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "tmi_embed_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "tmi_xent_fwd_bwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_linear_xent": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_sum_scale": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "tmi_adam_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_vp, c_i32, c_i32, c_vp]),
     "tmi_adam_scalars": (c_i32, [c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_vp]),
@@ -118,7 +119,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 _lib = None
 
 

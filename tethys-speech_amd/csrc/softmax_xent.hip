@@ -71,10 +71,26 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
+// tmi_linear_xent: the operands of the LM head whose output the logits are.  bf16 logits lose the target logit's low bits
+// (ulp 0.03 at |z| in [4, 8)), and the loss is lse - z_target: measured on the headline golden, that rounding alone is up to
+// 6.5e-4 of the 7.7e-4 loss-curve error (profiles/r04_bf16_margin.txt).  With the operands at hand the row's workgroup
+// recomputes z_target = x[row, :] . w[:, target] in fp32 (d multiply-adds) for the LOSS; the gradient is unchanged.
+struct LmOperands {
+  const bf16_t* x;   // [rows, d], row stride x_ld; nullptr = plain cross-entropy
+  const bf16_t* w;   // element (k, n) at w[k * w_sk + n * w_sn]
+  int64_t x_ld, w_sk, w_sn;
+  int d;
+};
+__device__ __forceinline__ float lm_target_logit(const LmOperands& lm, int64_t row, int target, float* red) {
+  float z = 0.f;
+  for (int k = threadIdx.x; k < lm.d; k += 256) z = fmaf((float)lm.x[row * lm.x_ld + k], (float)lm.w[k * lm.w_sk + (int64_t)target * lm.w_sn], z);
+  return block_sum_256(z, red);
+}
+
 // One 256-thread block per logits row.  Pass 1: online (max, sum); pass 2: write gradient.
 template <typename T>
 __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
-                                                   float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
+                                                   float* __restrict__ row_loss, int S, int64_t V, float grad_scale, const LmOperands lm) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[4];
   const int64_t row = blockIdx.x;
@@ -112,7 +128,9 @@ __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64
   const float gsum = block_sum_256(part, red);
   const float lse = gmx + logf(gsum);
   const float inv = 1.0f / gsum;
-  if (threadIdx.x == 0) row_loss[row] = lse - to_f32(lr[target]);
+  float zt = 0.f;
+  if (lm.x) zt = lm_target_logit(lm, row, target, red);  // (uniform over the block)
+  if (threadIdx.x == 0) row_loss[row] = lse - (lm.x ? zt : to_f32(lr[target]));
   __syncthreads();  // the target logit is read before anyone overwrites it
   for (int64_t ch = threadIdx.x; ch < nch; ch += 256) {
     const u32x4 raw = reinterpret_cast<const u32x4*>(lr)[ch];
@@ -141,7 +159,8 @@ __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64
 // 800 rows ran as a full round plus a 32-row tail (64 us); at <= 128 VGPRs and 36 KiB four workgroups fit: one round.
 constexpr int XREG = 17, XLDS = 9, XR = XREG + XLDS;
 __global__ __launch_bounds__(256, 4) void xent_rows_bf16_kernel(bf16_t* __restrict__ logits, int64_t ld, const int32_t* __restrict__ labels,
-                                                                float* __restrict__ row_loss, int S, int64_t V, float grad_scale) {
+                                                                float* __restrict__ row_loss, int S, int64_t V, float grad_scale,
+                                                                const LmOperands lm) {
   __shared__ float red[4];
   __shared__ u32x4 spill[XLDS * 256];  // chunk XREG + k of thread t at spill[k * 256 + t]
   const int64_t row = blockIdx.x;
@@ -227,7 +246,9 @@ __global__ __launch_bounds__(256, 4) void xent_rows_bf16_kernel(bf16_t* __restri
   pin();
   const float gsum = block_sum_256(sum, red);
   const float inv = grad_scale / gsum;
-  if (threadIdx.x == 0) row_loss[row] = gmx + logf(gsum) - (float)lr[target];
+  float zt = 0.f;
+  if (lm.x) zt = lm_target_logit(lm, row, target, red);  // (uniform over the block)
+  if (threadIdx.x == 0) row_loss[row] = gmx + logf(gsum) - (lm.x ? zt : (float)lr[target]);
   __syncthreads();  // the target logit is read before anyone overwrites it
   const int tch = target >> 3, ti = target & 7;
   auto emit = [&](int ch, const u32x4& r) {
@@ -355,27 +376,44 @@ extern "C" int tmi_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t 
   return tmi_check_launch("tmi_softmax_bwd");
 }
 
-extern "C" int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
-                                int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream) {
+static int xent_launch(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V,
+                       float grad_scale, int32_t dtype, const LmOperands& lm, void* stream, const char* what) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!logits || !labels || !row_loss || B <= 0 || S <= 1 || V <= 0 || ld < V || ld % vec || !al16(logits)) {
-    tmi_set_error("tmi_xent_fwd_bwd: bad argument (ld must be a multiple of 16 bytes, >= V)");
+    tmi_set_error("tmi_xent_fwd_bwd / tmi_linear_xent: bad argument (ld must be a multiple of 16 bytes, >= V)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   dim3 grid((unsigned)(B * S));
   static const int gen = [] { const char* e = getenv("TMI_XENT_GENERIC"); return e ? atoi(e) : 0; }();
   if (dtype == TMI_BF16 && !gen && ld <= (int64_t)256 * 8 * XR)
-    hipLaunchKernelGGL(xent_rows_bf16_kernel, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V, grad_scale);
+    hipLaunchKernelGGL(xent_rows_bf16_kernel, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V, grad_scale, lm);
   else if (dtype == TMI_BF16)
     hipLaunchKernelGGL(xent_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)logits, ld, labels, row_loss, (int)S, V,
-                       grad_scale);
+                       grad_scale, lm);
   else if (dtype == TMI_F32)
     hipLaunchKernelGGL(xent_kernel<float>, grid, dim3(256), 0, s, (float*)logits, ld, labels, row_loss, (int)S, V,
-                       grad_scale);
+                       grad_scale, LmOperands{});  // (fp32 logits carry their target logit exactly)
   else
     return TMI_ERR_UNSUPPORTED;
-  return tmi_check_launch("tmi_xent_fwd_bwd");
+  return tmi_check_launch(what);
+}
+
+extern "C" int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
+                                int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream) {
+  return xent_launch(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, LmOperands{}, stream, "tmi_xent_fwd_bwd");
+}
+
+extern "C" int tmi_linear_xent(const void* x, int64_t x_ld, const void* w, int64_t w_sk, int64_t w_sn, int64_t d, void* logits,
+                               int64_t ld, const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V,
+                               float grad_scale, int32_t dtype, void* stream) {
+  if (!x || !w || d <= 0 || d > (1 << 20) || x_ld < d || w_sk == 0 || w_sn == 0) {
+    tmi_set_error("tmi_linear_xent: bad LM-head operands");
+    return TMI_ERR_INVALID;
+  }
+  LmOperands lm{};
+  if (dtype == TMI_BF16) lm = LmOperands{(const bf16_t*)x, (const bf16_t*)w, x_ld, w_sk, w_sn, (int)d};
+  return xent_launch(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, lm, stream, "tmi_linear_xent");
 }
 
 extern "C" int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stream) {

@@ -379,10 +379,17 @@ def embed_bwd(labels, dy, dtable, B, S, D, start_id):
                               dt(dy), stream()), "tmi_embed_bwd")
 
 
-def xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale):
+def xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale, lm=None):
+    """``lm = (x, x_ld, w, w_sk, w_sn, d)``: the logits are the LM head's output x . w - tmi_linear_xent takes the target logit of
+    the loss from those operands in fp32 instead of from the bf16-rounded logits."""
     with _probe("xent", 3.0 * B * S * V * logits.element_size()):
-        check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
-                                     grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
+        if lm is None:
+            check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
+                                         grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
+        else:
+            x, x_ld, w, w_sk, w_sn, d = lm
+            check(lib().tmi_linear_xent(x.data_ptr(), x_ld, w.data_ptr(), w_sk, w_sn, d, logits.data_ptr(), ld, labels.data_ptr(),
+                                        row_loss.data_ptr(), B, S, V, grad_scale, dt(logits), stream()), "tmi_linear_xent")
 
 
 def sum_scale(x, out, n, scale):

@@ -36,6 +36,9 @@ SITE_ENC_STEM, SITE_DEC_EMBED = 1, 2
 SITE_ENC_ATTN, SITE_ENC_FFN, SITE_DEC_SELF, SITE_DEC_CROSS, SITE_DEC_FFN = 100, 200, 300, 400, 500
 
 
+_XENT_EXACT = os.environ.get("TMI_XENT_EXACT_TARGET", "1") != "0"
+
+
 @dataclass
 class WhisperConfig:  # W:10-45
     d_model: int = 768
@@ -552,7 +555,10 @@ class WhisperForConditionalGeneration(KernelBlocks):
         Vp = self.ldl  # pad columns of the stored kernel are zero: their logits are 0 and ignored by xent
         self._gemm_xw(ws["dec_out"], "lm_head.kernel", logits, B * S, Vp, d, d, ldc=Vp)
         gs = loss_scale / (B * (S - 1))
-        ops.xent_fwd_bwd(logits, self.ldl, labels, ws["row_loss"], B, S, V, gs)
+        # (tmi_linear_xent: the loss's target logit in fp32 from the LM head's own operands - bf16 logits have lost its low bits;
+        # TMI_XENT_EXACT_TARGET=0: the plain cross-entropy of the stored logits)
+        lm = (ws["dec_out"], d, wl, ldw, 1, d) if _XENT_EXACT else None
+        ops.xent_fwd_bwd(logits, self.ldl, labels, ws["row_loss"], B, S, V, gs, lm=lm)
         ops.sum_scale(ws["row_loss"], ws["loss"], B * S, 1.0 / (B * (S - 1)))
 
         # ================= backward =================
