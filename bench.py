@@ -413,8 +413,20 @@ def self_launch(gpus, script=None, argv=None):
     line = None
     for out in child.stdout:
         out = out.rstrip("\n")
-        if out.startswith("{") and '"metric"' in out:
-            line = out  # held back: it must be the last line of OUR stdout
+        # rank 0's JSON object, wherever it sits in the line: the ranks share one pipe, and another rank's (or a library's)
+        # output can land in the middle of a line of rank 0's
+        at = out.find('{"metric"')
+        obj = None
+        if at >= 0:
+            try:
+                obj, end = json.JSONDecoder().raw_decode(out[at:])
+            except ValueError:
+                obj = None
+        if isinstance(obj, dict):
+            line = json.dumps(obj)  # held back: it must be the last line of OUR stdout
+            rest = (out[:at] + out[at + end:]).strip()
+            if rest:
+                print(rest, flush=True)
         else:
             print(out, flush=True)
     rc = child.wait()
@@ -590,8 +602,11 @@ def main():
             else:
                 out["cpu_baseline"] = cpu_baseline_w2v(size, args.batch_size, dev, args.cpu_budget,
                                                        single=args.workload == "whisper_single")
-        print(json.dumps(out))
+        # ONE write: the line must not be cut in two by another rank's output on the shared pipe
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
     if world > 1:
+        strategy.barrier()  # the other ranks stay silent until the line is out: library teardown messages come after it
         torch.distributed.destroy_process_group()
 
 
