@@ -119,3 +119,17 @@ def test_restore_in_place_resets_row_sparse_flags(dev, tmp_path):
     o2.row_sparse = True
     run(m2, o2, [late[1]]); run(md, od, [late[1]])
     same_state(m2, md)
+    # the flags are (re)created by a fill on torch's current stream while tmi_adam_step_rows reads and writes them on
+    # the stream ops is pinned to (the second stream, for the early slice).  Invalidate them and step with either stream held
+    # back by a long sleep kernel: a fill that lands after the row kernel would re-mark touched rows idle (or hand it
+    # uninitialised flags) and those rows stop moving - same_state against the dense run shows it.
+    for held in ("main", "side"):
+        optim.Adam.invalidate_row_flags(m2)
+        assert not m2.arena.adam_row_flags
+        st = torch.cuda.current_stream() if held == "main" else m2._side
+        if st is not None:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(int(3e7))  # ~12 ms at 2.4 GHz: longer than the whole step
+        run(m2, o2, [late[2]]); run(md, od, [late[2]])
+        assert m2.arena.adam_row_flags
+        same_state(m2, md)
