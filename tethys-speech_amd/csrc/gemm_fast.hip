@@ -67,14 +67,14 @@ struct FastParams {
 // epilogue tests every feature of tmi_gemm_desc per pass with all of its pointers live (it measured ~800 instructions
 // and ~4.8 k cycles per piece with two waves per SIMD, whatever the features in use); a class is straight-line code.
 constexpr int EPI_GENERIC = 0, EPI_SIMPLE = 1 /* bias, scale, GELU + saved pre-activation */, EPI_AUXIN = 2 /* x GELU'(aux_in) */,
-              EPI_RESID = 3 /* bias, dropout, + residual */, EPI_ACC = 4 /* C += */;
+              EPI_RESID = 3 /* bias, [saved pre-activation, GELU,] dropout, + residual */, EPI_ACC = 4 /* C += */;
 inline int epi_class(const tmi_gemm_desc& d, bool wide) {
   static const int off = [] { const char* e = getenv("TMI_GEMM_LEAN_EPI"); return e && atoi(e) == 0; }();
   if (off || !wide || (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15 || d.bias_sb % 4))) return EPI_GENERIC;
   const bool drop = d.dropout_p > 0.f;
   if (d.accumulate) return (!d.aux_in && !d.resid && !d.act && !d.aux_out && !drop && d.scale_cols <= 0) ? EPI_ACC : EPI_GENERIC;
   if (d.aux_in) return (!d.resid && !d.act && !d.aux_out && !drop && d.scale_cols <= 0) ? EPI_AUXIN : EPI_GENERIC;
-  if (d.resid) return (!d.act && !d.aux_out && d.scale_cols <= 0) ? EPI_RESID : EPI_GENERIC;
+  if (d.resid) return d.scale_cols <= 0 ? EPI_RESID : EPI_GENERIC;  // (+ GELU and the saved pre-activation: the conv stem, W:311-342)
   return drop ? EPI_GENERIC : EPI_SIMPLE;
 }
 
@@ -316,7 +316,7 @@ __device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, in
   if constexpr (CLS == EPI_AUXIN) xp = reinterpret_cast<const TC*>(d.aux_in) + bz * d.c_sb + off0;
   if constexpr (CLS == EPI_RESID) { xp = reinterpret_cast<const TC*>(d.resid) + bz * d.r_sb + (mw + rsub) * d.r_ld + n; xstep = 8 * d.r_ld; }
   if constexpr (CLS == EPI_ACC) xp = cp;
-  TC* ap = (CLS == EPI_SIMPLE && d.aux_out) ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb + off0 : nullptr;
+  TC* ap = ((CLS == EPI_SIMPLE || CLS == EPI_RESID) && d.aux_out) ? reinterpret_cast<TC*>(d.aux_out) + bz * d.c_sb + off0 : nullptr;
 #pragma unroll
   for (int pp = 0; pp < 4; pp += AHEAD) {
     raw_t x[AHEAD];
@@ -346,6 +346,13 @@ __device__ __forceinline__ void lean_rows(const FastParams& P, const char* E, in
           for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
         }
       } else {
+        if constexpr (CLS == EPI_RESID) {  // (the conv stem: x = GELU(u) + PE with u saved; uniform tests, off for the FFN / out-proj launches)
+          if (ap) Vec8<TC>::store(ap + (pp + j) * step, v);
+          if (d.act == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
+          }
+        }
         Vec8<TC>::widen(x[j], t);
         if constexpr (CLS == EPI_AUXIN) {
 #pragma unroll
@@ -1779,7 +1786,10 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     static const int p8_all = [] { const char* e = getenv("TMI_GEMM_P8_ALL"); return e ? atoi(e) : 0; }();  // (off: level or +0.04 ms in the step, profiles/r04_step_ab_p8_all.txt)
     // (round 4: the LM head's forward, [800, 51904] from K = 768 - 812 tiles walked by the persistent form: 127 -> 111 us)
     static const int wide_on = [] { const char* e = getenv("TMI_GEMM_P8_WIDE"); return e ? atoi(e) : 1; }();
-    const bool m_ok = d.M >= 2048 || (p8_all && d.M >= 1024 && d.M * d.nbatch >= 4096) || (wide_on && d.M >= 512 && big_tiles >= 512);
+    // (round 4: batched launches count their batches - the conv2 forward is 8 x [1500, 768] x K 2304; TMI_GEMM_P8_BATCHED=0: the 128x128 kernel)
+    static const int p8_batched = [] { const char* e = getenv("TMI_GEMM_P8_BATCHED"); return e ? atoi(e) : 1; }();
+    const bool m_ok = d.M >= 2048 || ((p8_all || (p8_batched && d.K >= 1024)) && d.M >= 1024 && d.M * d.nbatch >= 4096) ||
+                      (wide_on && d.M >= 512 && big_tiles >= 512);
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && m_ok && d.N >= 256) {
       if (d.M < 1024) return launch_p8<TC, false, B_KS>(d, stream);  // (the LM head's forward: 256-row tiles measured ahead of 192)
       // 192-row tiles when they need fewer CU-rounds of work: cost = rounds of 256 workgroups x tile rows
