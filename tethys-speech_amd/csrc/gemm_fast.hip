@@ -1788,7 +1788,9 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
     static const int wide_on = [] { const char* e = getenv("TMI_GEMM_P8_WIDE"); return e ? atoi(e) : 1; }();
     // (round 4: batched launches count their batches - the conv2 forward is 8 x [1500, 768] x K 2304; TMI_GEMM_P8_BATCHED=0: the 128x128 kernel)
     static const int p8_batched = [] { const char* e = getenv("TMI_GEMM_P8_BATCHED"); return e ? atoi(e) : 1; }();
-    const bool m_ok = d.M >= 2048 || ((p8_all || (p8_batched && d.K >= 1024)) && d.M >= 1024 && d.M * d.nbatch >= 4096) ||
+    // (>= 160 of its 192-row tiles: Wav2Vec2's conv3, 8 x [1600, 512] x K 1536 = 144 tiles, runs 38 us on the 128x128 kernel and 46 here)
+    const bool fills = ((d.M + 191) / 192) * ((d.N + 255) / 256) * d.nbatch >= 160;
+    const bool m_ok = d.M >= 2048 || ((p8_all || (p8_batched && d.K >= 1024 && fills)) && d.M >= 1024 && d.M * d.nbatch >= 4096) ||
                       (wide_on && d.M >= 512 && big_tiles >= 512);
     if (!no_p8 && force < 0 && !wgrad_like && d.splitk <= 1 && p8_eligible(d, false, B_KS) && m_ok && d.N >= 256) {
       if (d.M < 1024) return launch_p8<TC, false, B_KS>(d, stream);  // (the LM head's forward: 256-row tiles measured ahead of 192)
