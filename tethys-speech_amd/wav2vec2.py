@@ -281,7 +281,10 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         self._buf("quant", (R, cd))
         self._buf("code_idx", (R, cfg.num_codevector_groups), torch.int32)
         self._buf("perplexity", (1,), f32)
-        self._buf("pq_pre", (R, pd)); self._buf("pq", (R, pd))
+        self._buf("pq_pre", (R, pd))
+        # (64 zero rows behind the last batch: the backward's dS . pq runs its reduction over the PADDED row length of dS -
+        # a whole number of K-tiles - and reads up to 63 rows past a batch's T: the next batch's, or these)
+        self.ws["pq"] = self._buf("pq_pad", (R + 64, pd), zero=True)[:R]
         self._buf("pq_ln.mean", (R,), f32); self._buf("pq_ln.rstd", (R,), f32)
         self._buf("ph_pre", (R, pd)); self._buf("ph", (R, pd))
         self._buf("ph_ln.mean", (R,), f32); self._buf("ph_ln.rstd", (R,), f32)
@@ -305,7 +308,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                 self._buf(p + "P", (B, cfg.num_attention_heads, self.T, self.T), f32)
         self._buf("enc_x", (R, H))
         self._buf("S", (B, self.T, self.T), f32)
-        self._buf("dS", (B, self.T, (self.T + 7) // 8 * 8))  # bf16 copy of dS, rows padded to whole 16-byte chunks
+        self._buf("dS", (B, self.T, (self.T + 63) // 64 * 64))  # bf16 copy of dS, rows padded to whole 64-element K-tiles (zeros)
         self._buf("row_loss", (R,), f32)
         self._buf("closs", (1,), f32)
         self._buf("loss", (1,), f32)
@@ -472,7 +475,10 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         else:
             dS, Tp = S, T
         # d ph = dS · pq ; d pq = dSᵀ · ph   (per batch)
-        ops.gemm(dS, ws["pq"], ws["dph"], T, pd, T, Tp, 1, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
+        # (K = Tp, not T: the pad columns of dS are zeros (tmi_cast_bf16 writes them), so the extra products vanish and the
+        # launch takes the LDS-DMA kernels, whose k-contiguous operands come in whole 64-element K-tiles - with K = 99 it was
+        # the step's only generic-kernel GEMM, 33 us for 40 MFLOP)
+        ops.gemm(dS, ws["pq"], ws["dph"], T, pd, Tp, Tp, 1, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
         ops.gemm(dS, ws["ph"], ws["dpq"], T, pd, T, 1, Tp, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
         if drop:
             self._dropout(ws["dpq"], ws["dpq"], SITE_PQ)
