@@ -199,10 +199,19 @@ typedef struct tmi_attn_desc {
   float dq_scale;              /* dq is multiplied by this on store (chain rule of W:141) */
   float score_scale;           /* scores = (q . k) * score_scale (V:349 divides AFTER q.k^T); 0 means 1 */
   /* Dropout on the attention probabilities (W:160), training mode: 0 <= dropout_p < 1, 0 = off.  The keep
-   * mask is a function of (dropout_seed, b, head, q, k), regenerated by the backward kernels (see tmi_dropout);
-   * the row sums that normalise the probabilities are taken before dropping, as tf.nn.softmax -> Dropout does. */
+   * mask is a function of (dropout_seed, b, head, q, k) (tmi_common.h: tmi_keep_attn; oracle/dropout.py keep_attention);
+   * the row sums that normalise the probabilities are taken before dropping, as tf.nn.softmax -> Dropout does.
+   * TensorFlow draws the mask once and keeps it for the gradient (W:160): so does this pair of entry points -
+   * tmi_attn_fwd evaluates the generator and stores 1 keep bit per score into `drop_mask`, tmi_attn_bwd reads the
+   * bits and never hashes.  drop_mask: 16-byte aligned device buffer of tmi_attn_dropmask_bytes(B, H, Tq, Tk) bytes
+   * owned by the caller from the forward call to the backward call of the same descriptor; required when
+   * dropout_p > 0 (TMI_ERR_INVALID otherwise), ignored when dropout_p == 0.  Layout (private to the two entry
+   * points): u32 words [B*H][ceil(Tk/64)][2][ceil(Tq/128)*128], one word = the 32 keys a forward lane holds of one
+   * 64-key tile. */
   float dropout_p;
   uint64_t dropout_seed;
+  void* drop_mask;
+  int64_t drop_mask_bytes;
   /* Optional fp32 scratch (16-byte aligned, tmi_attn_workspace_bytes(B, H, Tq) bytes; NULL = none).  With it, the forward
    * and dQ passes of a short query side against a long key side (one query tile, >= 8 key tiles of 64, mask_mode 0: the
    * cross-attention of W:255-301) split the keys over 2-8 workgroups per (batch, head) and fold the partials in a second
@@ -215,6 +224,7 @@ typedef struct tmi_attn_desc {
   int32_t bwd_passes;
 } tmi_attn_desc;
 int64_t tmi_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tq);
+int64_t tmi_attn_dropmask_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk);
 int tmi_attn_fwd(const tmi_attn_desc* d, void* stream);
 int tmi_attn_bwd(const tmi_attn_desc* d, void* stream);
 

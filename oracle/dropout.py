@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE (checker only): numpy restatement of the counter-based dropout generator of
-tethys-speech_amd/csrc/tmi_common.h (tmi_mix32 / tmi_row_key / tmi_pair_hash / tmi_stream_key / tmi_keep).
+tethys-speech_amd/csrc/tmi_common.h (tmi_mix32 / tmi_row_key / tmi_pair_hash / tmi_stream_key / tmi_keep, and the attention
+kernels' tmi_quad_hash / tmi_keep_attn).
 
 The reference applies tf.keras.layers.Dropout in training (speech_jobs/whisper_dist.py:160, 205, 342, 411);
 TensorFlow's RNG stream cannot be reproduced, so the masks below are this build's own and parity with
@@ -75,13 +76,34 @@ def keep_flat(seed, rows, cols, p):
     return keep_rows(stream_key(seed, 0), rows, cols, drop_thr(p))
 
 
+def quad_hash(rk, cq):
+    """tmi_quad_hash: two 32-bit words (ha, hb) for column quad ``cq`` (= column >> 2) of the row with key ``rk``: the
+    attention generator - one evaluation serves the four consecutive keys a forward lane holds in one accumulator quad."""
+    ra, rb = rk
+    h = _mul24(_u32(ra) ^ _u32(cq), 0x9E3779)
+    h = h ^ (h >> np.uint64(15)) ^ _u32(rb)
+    return _mul24(h, 0x85EBCB), _mul24(h, 0xC2B2AE)
+
+
+def keep_rows_attention(key, rows, cols, thr):
+    """tmi_keep_attn over a [rows, cols] grid of one stream: column 4cq + {0, 1, 2, 3} draws the {low, high} half of
+    {ha, hb} as a SIGNED 16-bit number and is kept when draw >= thr - 32768."""
+    r = np.arange(rows, dtype=np.uint64)[:, None]
+    c = np.arange(cols, dtype=np.uint64)[None, :]
+    ha, hb = quad_hash(row_key(key, r), c >> np.uint64(2))
+    w = np.where(c & np.uint64(2), hb, ha)
+    d = np.where(c & np.uint64(1), w >> np.uint64(16), w & np.uint64(0xFFFF)).astype(np.uint16).view(np.int16)
+    return d.astype(np.int32) >= (int(thr) - 32768)
+
+
 def keep_attention(seed, B, H, Tq, Tk, p):
-    """[B, H, Tq, Tk] bool mask of the attention kernels: stream b*H + head, row = query, column = key."""
+    """[B, H, Tq, Tk] bool mask of the attention kernels (tmi_attn_fwd draws it and stores it, tmi_attn_bwd reads the
+    stored bits): stream b*H + head, row = query, column = key."""
     out = np.empty((B, H, Tq, Tk), dtype=bool)
     thr = drop_thr(p)
     for b in range(B):
         for h in range(H):
-            out[b, h] = keep_rows(stream_key(seed, b * H + h), Tq, Tk, thr)
+            out[b, h] = keep_rows_attention(stream_key(seed, b * H + h), Tq, Tk, thr)
     return out
 
 

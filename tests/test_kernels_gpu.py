@@ -534,6 +534,24 @@ def _attn_ref(q, k, v, mask_mode, keep=None, keep_scale=1.0):
     return p @ v
 
 
+def _decode_dropmask(dm, B, H, Tq, Tk):
+    """The stored keep bits of tmi_attn_fwd (include/tethys_mi.h: drop_mask; layout in csrc/attention.hip at mask_pos) as a
+    [B, H, Tq, Tk] bool array."""
+    import numpy as np
+    NT, TQP = (Tk + 63) // 64, (Tq + 127) // 128 * 128
+    w = dm.cpu().numpy().view(np.uint32).reshape(B * H, NT, 2, TQP)
+    q = np.arange(Tq)
+    rr = q & 31
+    qpos = (q & ~63) + (q & 32) + 2 * ((rr & 3) + 4 * (rr >> 3)) + ((rr >> 2) & 1)
+    k = np.arange(Tk)
+    t, kk = k // 64, k % 64
+    hh = (kk >> 2) & 1
+    j = 8 * (kk >> 5) + 2 * ((kk >> 3) & 3) + ((kk >> 1) & 1)
+    bit = j + 16 * (kk & 1)
+    words = w[:, t[None, :], hh[None, :], qpos[:, None]]          # [BH, Tq, Tk]
+    return ((words >> bit[None, None, :].astype(np.uint32)) & 1).astype(bool).reshape(B, H, Tq, Tk)
+
+
 @pytest.mark.parametrize("B,H,Tq,Tk,mask,drop", [(2, 3, 100, 100, 1, 0.0), (1, 2, 200, 333, 0, 0.0), (2, 2, 100, 1500, 0, 0.0),
                                                  (1, 1, 31, 31, 1, 0.0), (1, 12, 1500, 1500, 0, 0.0),
                                                  (2, 3, 100, 100, 1, 0.1), (1, 2, 200, 333, 0, 0.1), (2, 2, 100, 1500, 0, 0.25),
@@ -552,15 +570,22 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     o = torch.empty((B, Tq, D), dtype=bf, device=dev)
     stats = torch.empty((B, H, Tq, 2), dtype=torch.float32, device=dev)
     seed = 0x1234ABCD5678 + Tq
+    # W:160: the mask is drawn once, in the forward, and kept for the gradient (1 bit per score in a caller-owned buffer)
+    dmask = ops.attn_dropmask(dev, B, H, Tq, Tk) if drop > 0 else None
+    if dmask is not None:
+        dmask.fill_(0xA5)  # every word the backward reads must have been written by the forward
     ops.attn_fwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats, B, H, Tq, Tk, mask,
-                 dropout_p=drop, dropout_seed=seed)
+                 dropout_p=drop, dropout_seed=seed, drop_mask=dmask)
     torch.cuda.synchronize()
     keep, ks = None, 1.0
     if drop > 0:  # the generator restated on the host: the kernels must drop exactly these probabilities
         from oracle import dropout as DO
-        keep = torch.from_numpy(DO.keep_attention(seed, B, H, Tq, Tk, drop)).double()
+        keep_np = DO.keep_attention(seed, B, H, Tq, Tk, drop)
+        keep = torch.from_numpy(keep_np).double()
         ks = DO.keep_scale(drop)
         assert abs(float(keep.mean()) - (1.0 - drop)) < 0.01
+        # the bits the forward stored for the backward ARE the generator's output, bit for bit
+        assert (_decode_dropmask(dmask, B, H, Tq, Tk) == keep_np).all()
 
     def heads(t, T):
         return t.double().cpu().reshape(B, T, H, 64).permute(0, 2, 1, 3)
@@ -577,7 +602,7 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     delta = torch.empty((B, H, Tq), dtype=torch.float32, device=dev)
     ops.attn_bwd((q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D), stats,
                  (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D), (dv, 0, Tk * D, D), delta,
-                 B, H, Tq, Tk, mask, dq_scale=0.5, dropout_p=drop, dropout_seed=seed)
+                 B, H, Tq, Tk, mask, dq_scale=0.5, dropout_p=drop, dropout_seed=seed + 1, drop_mask=dmask)  # (the backward never hashes: its seed is unused)
     torch.cuda.synchronize()
 
     def merge(t, T):

@@ -286,8 +286,11 @@ def test_dropout_generator_known_answers_and_statistics():
     assert abs(D.keep_scale(0.1) - 65536.0 / (65536 - 6554)) < 1e-6
     assert D.keep_flat(42, 4, 8, 0.1).astype(int).tolist() == [[1, 0, 1, 1, 0, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1, 0],
                                                               [0, 1, 0, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 1, 1]]
+    # the attention generator (tmi_quad_hash / tmi_keep_attn: one evaluation per four keys, signed 16-bit draws); the frozen
+    # values come from a scalar restatement in plain Python integers, not from the numpy code they pin
+    assert [int(x) for x in D.quad_hash(D.row_key(0xDEADBEEF, 12345), 77)] == [1512887188, 2932179144]
     assert D.keep_attention(42, 1, 2, 3, 6, 0.5).astype(int).tolist() == \
-        [[[[1, 0, 1, 0, 0, 1], [1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 1, 1]], [[0, 1, 0, 0, 0, 0], [1, 0, 1, 0, 0, 1], [1, 0, 1, 0, 0, 0]]]]
+        [[[[0, 1, 0, 1, 0, 1], [0, 1, 0, 0, 0, 1], [1, 0, 0, 1, 1, 1]], [[1, 0, 1, 0, 1, 1], [0, 1, 0, 0, 0, 1], [0, 1, 0, 1, 0, 1]]]]
     assert D.site_seed(0xC0FFEE, 3, 204) == 17806544269414322833
     assert D.site_id("decoder.layers.3.encoder_attn") == 403 and D.w2v_site_id("encoder.layers.11.attention_output") == 211
     m = D.keep_flat(7, 600, 768, 0.1)
@@ -295,9 +298,21 @@ def test_dropout_generator_known_answers_and_statistics():
     assert abs(m.mean() - (1 - 6554 / 65536)) < 4 * (0.3 / np.sqrt(n))
     for a, b in ((m[:, :-1], m[:, 1:]), (m[:-1], m[1:]), (m[:, :-2], m[:, 2:])):
         assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 5 / np.sqrt(n)
-    att = D.keep_attention(11, 2, 4, 96, 160, 0.1).reshape(8, -1).astype(float)
+    att4 = D.keep_attention(11, 2, 4, 96, 160, 0.1)
+    att = att4.reshape(8, -1).astype(float)
     c = np.corrcoef(att)
     assert np.abs(c - np.eye(8)).max() < 5 / np.sqrt(att.shape[1])      # streams (batch, head)
+    # the attention mask behaves like independent draws too: rate, neighbours along keys and queries, and the four draws
+    # that share one generator evaluation (keys 4cq .. 4cq+3) pairwise
+    big = D.keep_attention(3, 1, 2, 512, 1024, 0.1)[0]
+    nb = big.size
+    assert abs(big.mean() - (1 - 6554 / 65536)) < 4 * (0.3 / np.sqrt(nb))
+    for a, b in ((big[..., :-1], big[..., 1:]), (big[:, :-1], big[:, 1:]), (big[..., :-4], big[..., 4:])):
+        assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 5 / np.sqrt(nb)
+    quad = big.reshape(2, 512, 256, 4)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(np.corrcoef(quad[..., i].ravel(), quad[..., j].ravel())[0, 1]) < 5 / np.sqrt(nb / 4)
     s0 = D.keep_flat(D.site_seed(5, 0, 100), 300, 256, 0.1).ravel().astype(float)
     s1 = D.keep_flat(D.site_seed(5, 1, 100), 300, 256, 0.1).ravel().astype(float)
     s2 = D.keep_flat(D.site_seed(5, 0, 101), 300, 256, 0.1).ravel().astype(float)

@@ -52,6 +52,7 @@ class AttnDesc(C.Structure):
         ("score_scale", c_f32),
         ("dropout_p", c_f32),
         ("dropout_seed", C.c_uint64),
+        ("drop_mask", c_vp), ("drop_mask_bytes", c_i64),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("bwd_passes", c_i32),
     ]
@@ -74,6 +75,7 @@ SIGNATURES = {
     "tmi_softmax_fwd": (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i32, c_vp]),
     "tmi_softmax_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp]),
     "tmi_attn_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "tmi_attn_dropmask_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "tmi_attn_fwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "tmi_attn_bwd": (c_i32, [C.POINTER(AttnDesc), c_vp]),
     "tmi_embed_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_i32, c_vp]),
@@ -119,7 +121,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 _lib = None
 
 

@@ -516,7 +516,8 @@ class KernelBlocks:
             ops.attn_fwd((qt, qo, Tq * qt.stride(0), qt.stride(0)), (kt, ko, Tk * kt.stride(0), kt.stride(0)),
                          (vt, vo, Tk * vt.stride(0), vt.stride(0)), (ctx2d, 0, Tq * d, d),
                          self.ws[key], B, H, Tq, Tk, mask, score_scale=score_scale,
-                         dropout_p=dp, dropout_seed=self._site_seed(site) if dp > 0 else 0)
+                         dropout_p=dp, dropout_seed=self._site_seed(site) if dp > 0 else 0,
+                         drop_mask=self._attn_dropmask(key, B, H, Tq, Tk) if dp > 0 else None)
             return
         # fp32 parity mode (W:147-167 as written: scores materialised).  One launch per product over all (sample, head)
         # pairs: heads are the inner batch level (stride hd inside a token row), samples the outer one (tmi_gemm nbatch2)
@@ -528,6 +529,11 @@ class KernelBlocks:
         ops.softmax_fwd(P, B * H * Tq, Tq, Tk, mask)
         ops.gemm(P, vt, ctx2d, Tq, hd, Tk, Tk, 1, vt.stride(0), 1, d, nbatch=H, a_sb=Tq * Tk, b_sb=hd, c_sb=hd,
                  b_off=vo, nbatch2=B, a_sb2=H * Tq * Tk, b_sb2=Tk * vt.stride(0), c_sb2=Tq * d)
+
+    def _attn_dropmask(self, key, B, H, Tq, Tk):
+        """The stored keep bits of attention call ``key`` (W:160: TF keeps the mask it drew for the gradient): one buffer per
+        call site, alive from its forward to its backward like the softmax statistics next to it."""
+        return self._buf(key + ".dropmask", (int(ops.lib().tmi_attn_dropmask_bytes(B, H, Tq, Tk)),), torch.uint8)
 
     def _attn_bwd(self, key, q, k, v, ctx2d, dctx2d, dq, dk, dv, B, H, Tq, Tk, mask, score_scale=1.0,
                   q_prescaled=True, site=None, dkv_on_side=False):
@@ -553,7 +559,8 @@ class KernelBlocks:
                              B, H, Tq, Tk, mask, dq_scale=scaling if q_prescaled else 1.0, score_scale=score_scale,
                              dropout_p=self._drop_attn_p if site is not None else 0.0,
                              dropout_seed=self._site_seed(site) if (site is not None and self._drop_attn_p > 0) else 0,
-                             passes=passes)
+                             passes=passes,
+                             drop_mask=self._attn_dropmask(key, B, H, Tq, Tk) if (site is not None and self._drop_attn_p > 0) else None)
             if split:
                 run(1)
                 self._run_on_side(lambda: run(2), dctx2d)

@@ -35,6 +35,7 @@
 // 32 cycles, v_exp_f32 costs 8 issue cycles and every other vector op 4.
 #include "tmi_common.h"
 #include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 namespace {
@@ -45,6 +46,34 @@ constexpr int IMG = TROWS * 128;      // bytes of one [64][64] bf16 image
 
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 __device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// ---- stored dropout mask (tmi_attn_desc.drop_mask): u32 words [B*H][NT = ceil(Tk/64)][2][TQP = ceil(Tq/128)*128].
+// Word (bh, t, h, q) = the keep bits of the 32 scores that the forward lane (query q, lane half h) holds of key tile t:
+// bit j (j = 0..15) = the even key of pair j, bit 16 + j = its odd key, pair j = 8 rbk + 2 g + jj <-> keys
+// 64 t + 32 rbk + 8 g + 4 h + 2 jj + {0, 1} (rbk = 32-key half of the tile, g = accumulator quad, jj = pair of the quad).
+// Inside a block of 64 query rows the words sit in the order the dK/dV kernel wants them as wave-wide select masks:
+// row r at position mask_pos(r), so that positions 2e, 2e + 1 of each 32-row half are rows acc_row(e, 0), acc_row(e, 1) -
+// one aligned 64-bit scalar load = the select mask of accumulator register e over the wave's 64 lanes.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int mask_pos(int r) {
+  const int rr = r & 31;
+  return (r & 32) + 2 * ((rr & 3) + 4 * (rr >> 3)) + ((rr >> 2) & 1);
+}
+// 0xffff in each half whose SIGNED 16-bit draw is >= T (kept), given tm1 = (T - 1) in both halves: (T - 1) - d saturates
+// inside int16, so its sign is exact (v_pk_sub_i16 clamp + v_pk_ashrrev_i16)
+__device__ __forceinline__ uint32_t keep_pair(uint32_t hw, uint32_t tm1) {
+  const short2_t x = __builtin_elementwise_sub_sat(__builtin_bit_cast(short2_t, tm1), __builtin_bit_cast(short2_t, hw));
+  return __builtin_bit_cast(uint32_t, x >> (short2_t){15, 15});
+}
+// all ones when bit BIT of w is set (v_bfe_i32 of a 1-bit field sign-extends; hipcc rewrites the C form into and + cmp + cndmask)
+template <int BIT> __device__ __forceinline__ uint32_t bit_ones(uint32_t w) {
+  uint32_t t;
+  asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t) : "v"(w), "n"(BIT));
+  return t;
+}
+template <int... I, class F> __device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
 
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
@@ -147,15 +176,13 @@ __device__ __forceinline__ f32x16 first_product(const char* img, int rb, const b
   return x;
 }
 
-// Yt[blk][d][o] += sum_s T[rb + s][32 blk + d] * X[s][o]   (X = fp32 accumulator, s = 0..31)
-__device__ __forceinline__ void second_product(const char* img, int rb, const f32x16& x, f32x16 (&y)[2], int lane) {
+// Yt[blk][d][o] += sum_s T[rb + s][32 blk + d] * X[s][o]   (X as bf16 B operands: xb[sI][j] = X[8 sI + j][o])
+__device__ __forceinline__ void second_product_b(const char* img, int rb, const bf16x8 (&xb)[2], f32x16 (&y)[2], int lane) {
   const int g = lane >> 4, i = lane & 15;
   const int h = g >> 1, q = i >> 2, p = i & 3;
 #pragma unroll
   for (int sI = 0; sI < 2; ++sI) {
-    bf16x8 b;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = (bf16_t)x[8 * sI + j];
+    const bf16x8 b = xb[sI];
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       bf16x4 part[2];
@@ -170,6 +197,15 @@ __device__ __forceinline__ void second_product(const char* img, int rb, const f3
       y[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, y[blk], 0, 0, 0);
     }
   }
+}
+// the same with X still an fp32 accumulator (s = 0..31)
+__device__ __forceinline__ void second_product(const char* img, int rb, const f32x16& x, f32x16 (&y)[2], int lane) {
+  bf16x8 xb[2];
+#pragma unroll
+  for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[sI][j] = (bf16_t)x[8 * sI + j];
+  second_product_b(img, rb, xb, y, lane);
 }
 
 // write Yt[blk][d][o] * scale to out[o][d] (bf16), owner o on the lane
@@ -263,12 +299,19 @@ struct AttnP {
   uint32_t drop_thr;
   float keep_scale;
   uint32_t seed_lo, seed_hi;
+  uint32_t tm1;       // (thr - 32768 - 1) & 0xffff in both halves: keep_pair's threshold
+  uint32_t* dmask;    // the stored keep bits (layout at mask_pos above)
+  int NT, TQP;        // key tiles, padded query rows of dmask
+  // XCD-aware launch (gx > 0): a 1-D grid whose workgroup L works on (batch, head) pair (L % 8) + 8 * (L / 8 / gx) and on
+  // block (L / 8) % gx of it.  Workgroups are dealt round-robin over the 8 XCDs, so every workgroup of one (batch, head)
+  // lands on one XCD and the K / V (or Q / dO) rows they all stream stay in that XCD's 4 MiB L2 (speed only: nothing
+  // depends on the placement).  Needs B * H % 8 == 0.
+  int gx;
   // key split (forward and dQ passes of a short query side against a long key side: cross-attention, Tq <= 128): the
   // workgroups of one (batch, head) are `ksplit` disjoint key ranges; each leaves its un-normalised partial in `part`
   // ([B*H][ksplit][Tq][64] fp32, then for the forward [B*H][ksplit][Tq][2] = (m, l)) and a combine kernel folds them.
   int ksplit;
   float* part;
-  int dbg;  // TMI_ATTN_DBG (diagnostics)
 };
 
 // ABL (diagnostics, TMI_ATTN_ABL): 1 = no softmax arithmetic (p = s), 2 = no second product, 3 = no staging after the
@@ -280,9 +323,22 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const int ks = P.ksplit, qt = (int)blockIdx.x / ks, sp = (int)blockIdx.x - qt * ks;
+  int bx_, head_;
+  int64_t b_;
+  if (P.gx > 0) {
+    const int L = (int)blockIdx.x, r = L >> 3;
+    const int bh = (r / P.gx) * 8 + (L & 7);
+    bx_ = r % P.gx;
+    head_ = bh % (int)P.d.H;
+    b_ = bh / (int)P.d.H;
+  } else {
+    bx_ = (int)blockIdx.x;
+    head_ = (int)blockIdx.y;
+    b_ = (int64_t)blockIdx.z;
+  }
+  const int bx = bx_, head = head_;
+  const int64_t b = b_;
+  const int ks = P.ksplit, qt = bx / ks, sp = bx - qt * ks;
   const int q = qt * 128 + wave * 32 + c;
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
   const bool causal = d.mask_mode == 1;
@@ -298,9 +354,12 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
   f32x16 o[2];
   ZERO2(o);
   float m = -INFINITY, l = 0.f;
-  const uint32_t drop_thr = P.drop_thr;
+  const uint32_t tm1 = P.tm1;
   const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
   const tmi_rowkey qrk = tmi_row_key(skey, (uint32_t)q);  // the mask row of this lane's query: one avalanche per kernel
+  // this lane's column of the stored mask: word (b*H + head, tile, h, q); q < TQP for every lane of the grid
+  uint32_t* mrow = nullptr;
+  if constexpr (DROP) mrow = P.dmask + (((int64_t)(b * d.H + head) * P.NT) * 2 + h) * P.TQP + (q & ~63) + mask_pos(q & 63);
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
@@ -401,29 +460,52 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
       }
     }
     l += rs;
-    if constexpr (DROP) {  // zero the dropped probabilities; the kept ones are rescaled on the final store
+    if constexpr (DROP) {
+      // Dropout (W:160) on the bf16 operands of the second product: one generator evaluation per accumulator quad (4
+      // consecutive keys), two draws tested per packed op, the 0xffff / 0 masks ANDed onto the bf16 pairs and gathered into
+      // this lane's word of the stored mask (1 bit per score; the backward kernels read it instead of hashing).  The kept
+      // probabilities are rescaled on the final store.
+      bf16x8 pb[2][2];
 #pragma unroll
       for (int rbk = 0; rbk < 2; ++rbk)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const uint32_t hh = tmi_pair_hash(qrk, (uint32_t)((key0 + 32 * rbk + 8 * g + 4 * h) >> 1) + j);
-            if ((hh & 0xffffu) < drop_thr) s[rbk][4 * g + 2 * j] = 0.f;
-            if ((hh >> 16) < drop_thr) s[rbk][4 * g + 2 * j + 1] = 0.f;
+          for (int j = 0; j < 8; ++j) pb[rbk][sI][j] = (bf16_t)s[rbk][8 * sI + j];
+      const uint32_t x0 = qrk.a ^ (uint32_t)((key0 >> 2) + h);  // quad index of (rbk, g): (key0 >> 2) + h + 8 rbk + 2 g = base | const
+      uint32_t w = 0;
+#pragma unroll
+      for (int rbk = 0; rbk < 2; ++rbk) {
+        u32x4 u[2] = {__builtin_bit_cast(u32x4, pb[rbk][0]), __builtin_bit_cast(u32x4, pb[rbk][1])};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const tmi_quad hq = tmi_quad_hash_x(x0 ^ (uint32_t)(8 * rbk + 2 * g), qrk.b);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const uint32_t mk = keep_pair(jj ? hq.b : hq.a, tm1);
+            u[g >> 1][2 * (g & 1) + jj] &= mk;
+            // w |= mk & (0x00010001 << pair): one v_and_or_b32 (hipcc splits it into an AND per pair plus an OR3 tree)
+            asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(w) : "v"(mk), "s"(0x00010001u << (8 * rbk + 2 * g + jj)));
           }
-    }
+        }
+        pb[rbk][0] = __builtin_bit_cast(bf16x8, u[0]);
+        pb[rbk][1] = __builtin_bit_cast(bf16x8, u[1]);
+      }
+      mrow[(int64_t)tile * (2 * P.TQP)] = w;
+      second_product_b(Vimg, 0, pb[0], o, lane);
+      second_product_b(Vimg, 32, pb[1], o, lane);
+    } else
     if constexpr (ABL == 2) {
       asm volatile("" :: "v"(s[0]), "v"(s[1]));
     } else {
     second_product(Vimg, 0, s[0], o, lane);
     second_product(Vimg, 32, s[1], o, lane);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (with dropout the mask word is the youngest vector-memory operation of the tile: the seam waits for the DMA in front
+    // of it, the store's acknowledgement may arrive during the next tile)
+    if constexpr (DROP) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (P.dbg == 1) __builtin_amdgcn_s_sleep(20);
-    if (P.dbg == 2) __syncthreads();
-    if (P.dbg == 3) { __builtin_amdgcn_s_sleep(20); __syncthreads(); }
     if (ABL != 3) cur ^= 1;
   };
   const int nfast = causal ? 0 : min(Tk / TROWS, ntiles);  // full, unmasked tiles first
@@ -461,9 +543,22 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const int ks = P.ksplit, qt = (int)blockIdx.x / ks, sp = (int)blockIdx.x - qt * ks;
+  int bx_, head_;
+  int64_t b_;
+  if (P.gx > 0) {
+    const int L = (int)blockIdx.x, r = L >> 3;
+    const int bh = (r / P.gx) * 8 + (L & 7);
+    bx_ = r % P.gx;
+    head_ = bh % (int)P.d.H;
+    b_ = bh / (int)P.d.H;
+  } else {
+    bx_ = (int)blockIdx.x;
+    head_ = (int)blockIdx.y;
+    b_ = (int64_t)blockIdx.z;
+  }
+  const int bx = bx_, head = head_;
+  const int64_t b = b_;
+  const int ks = P.ksplit, qt = bx / ks, sp = bx - qt * ks;
   const int q = qt * 128 + wave * 32 + c;
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
   const bool causal = d.mask_mode == 1;
@@ -506,70 +601,64 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   const float nM = lg2(linv) - m;
   f32x16 dq[2];
   ZERO2(dq);
-  const uint32_t drop_thr = P.drop_thr;
-  const float keep_scale = P.keep_scale;
-  const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
-  const tmi_rowkey qrk = tmi_row_key(skey, (uint32_t)q);  // the mask row of this lane's query: one avalanche per kernel
+  const uint32_t ks_bits = __float_as_uint(P.keep_scale);
+  // the stored keep bits of this lane's scores: the word the forward lane of the same (query, lane half) wrote per key tile
+  const uint32_t* mrow = nullptr;
+  if constexpr (DROP) mrow = P.dmask + (((int64_t)(b * d.H + head) * P.NT) * 2 + h) * P.TQP + (q & ~63) + mask_pos(q & 63);
 
   const LaneSrc Ks = lane_src(kb, d.k_st, Tk, wave, lane);
   const LaneSrc Vs = lane_src(vb, d.v_st, Tk, wave, lane);
   const int ntiles_all = (Tk + TROWS - 1) / TROWS;
   const int per = (ntiles_all + ks - 1) / ks;
   const int t0 = sp * per, ntiles = min(ntiles_all, t0 + per);  // this workgroup's key tiles [t0, ntiles)
+  uint32_t wcur = 0;
+  if constexpr (DROP) wcur = mrow[(int64_t)t0 * (2 * P.TQP)];
   stage_tile(smem, Ks, t0 * TROWS, wave, lane);
   stage_tile(smem + IMG, Vs, t0 * TROWS, wave, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PIN(wcur);
   int cur = 0;
   auto body = [&](int tile, auto edge_tag) {
     constexpr bool edge = decltype(edge_tag)::value;
     const char* Kimg = smem + cur * 2 * IMG;
     const char* Vimg = Kimg + IMG;
+    uint32_t wnext = 0;
     if (tile + 1 < ntiles) {
       char* nx = smem + (cur ^ 1) * 2 * IMG;
       stage_tile(nx, Ks, (tile + 1) * TROWS, wave, lane);
       stage_tile(nx + IMG, Vs, (tile + 1) * TROWS, wave, lane);
+      if constexpr (DROP) wnext = mrow[(int64_t)(tile + 1) * (2 * P.TQP)];  // under this tile's MFMAs, like the DMA
     }
     const int key0 = tile * TROWS;
-#pragma unroll
-    for (int rbk = 0; rbk < 2; ++rbk) {
+    static_for(std::make_integer_sequence<int, 2>{}, [&](auto rbk_c) {
+      constexpr int rbk = decltype(rbk_c)::value;
       f32x16 s = first_product(Kimg, 32 * rbk, qf, c, h);    // s[key][q]
       f32x16 dp = first_product(Vimg, 32 * rbk, dof, c, h);  // dp[key][q]
-      // with dropout, d(p) = mask / keep * d(dropped p): one hash per pair of keys
-      auto dpm = [&](int e, uint32_t hh) -> float {
-        if constexpr (DROP) return ((e & 1) ? (hh >> 16) : (hh & 0xffffu)) < drop_thr ? 0.f : dp[e] * keep_scale;
-        else return dp[e];
-      };
-      // d(p) - delta with the mask as a factor of an fma (select on the constant, not on the product)
-      auto dpm_minus = [&](int e, uint32_t hh, float dl_) -> float {
-        if constexpr (DROP) return fmaf(dp[e], ((e & 1) ? (hh >> 16) : (hh & 0xffffu)) < drop_thr ? 0.f : keep_scale, -dl_);
-        else return dp[e] - dl_;
-      };
-      auto pair_draw = [&](int e) -> uint32_t {  // e even
-        if constexpr (DROP) return tmi_pair_hash(qrk, (uint32_t)((key0 + 32 * rbk + 8 * (e >> 2) + 4 * h) >> 1) + ((e >> 1) & 1));
-        else return 0u;
-      };
-      if constexpr (!edge) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const uint32_t hh = pair_draw(e);
-          s[e] = ex2(fmaf(s[e], c2, nM)) * dpm_minus(e, hh, delta);  // dS
-          s[e + 1] = ex2(fmaf(s[e + 1], c2, nM)) * dpm_minus(e + 1, hh, delta);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
+      // With dropout, d(p) = keep * keep_scale * d(dropped p): the factor is the keep bit of the score spread over a word
+      // (v_bfe_i32) and ANDed onto keep_scale - two instructions per score, no generator.  Bit of accumulator register e:
+      // pair 8 rbk + 2 (e >> 2) + ((e >> 1) & 1), + 16 for the odd key of the pair.
+      static_for(std::make_integer_sequence<int, 16>{}, [&](auto e_c) {
+        constexpr int e = decltype(e_c)::value;
+        float kf = 1.f;
+        if constexpr (DROP) kf = __uint_as_float(bit_ones<8 * rbk + 2 * (e >> 2) + ((e >> 1) & 1) + 16 * (e & 1)>(wcur) & ks_bits);
+        if constexpr (!edge) {
+          const float t = DROP ? fmaf(dp[e], kf, -delta) : dp[e] - delta;
+          s[e] = ex2(fmaf(s[e], c2, nM)) * t;  // dS
+        } else {
           const int key = key0 + 32 * rbk + acc_row(e, h);
           float x = s[e] * c2;
           if (causal && key <= q) x = x + MASKED2;
           const float pe = (key < Tk) ? ex2(x - m) * linv : 0.f;
-          s[e] = pe * (dpm(e, pair_draw(e & ~1)) - delta);
+          s[e] = pe * (DROP ? fmaf(dp[e], kf, -delta) : dp[e] - delta);
         }
-      }
+      });
       second_product(Kimg, 32 * rbk, s, dq, lane);  // dQt[d][q] += sum_key K[key][d] dS[key][q]
-    }
+    });
+    PIN(wnext);  // the compiler's wait for this load belongs here, not after the next iteration's DMA issue
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    wcur = wnext;
     cur ^= 1;
   };
   const int nfast = causal ? 0 : min(Tk / TROWS, ntiles);
@@ -585,7 +674,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
 }
 
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
-constexpr int NCONST = 6;  // per streamed query row: m, 1/l, delta, -(m + log2 l), the two dropout row-key words (bits)
+constexpr int NCONST = 4;  // per streamed query row: m, 1/l, delta (/ keep_scale with dropout), -(m + log2 l)
 template <bool DROP, int OCC>
 __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][NCONST][64] floats
@@ -593,9 +682,32 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
-  const int head = blockIdx.y;
-  const int64_t b = blockIdx.z;
-  const int key = blockIdx.x * 128 + wave * 32 + c;
+  int bx_, head_;
+  int64_t b_;
+  if (P.gx > 0) {
+    const int L = (int)blockIdx.x, r = L >> 3;
+    const int bh = (r / P.gx) * 8 + (L & 7);
+    bx_ = r % P.gx;
+    head_ = bh % (int)P.d.H;
+    b_ = bh / (int)P.d.H;
+  } else {
+    bx_ = (int)blockIdx.x;
+    head_ = (int)blockIdx.y;
+    b_ = (int64_t)blockIdx.z;
+  }
+  const int bx = bx_, head = head_;
+  const int64_t b = b_;
+  // Which key a lane owns is free (its K / V rows are gathered and its dK / dV rows scattered row by row anyway).  With
+  // dropout a wave owns the 32 keys of ONE word of the stored mask - key tile 2 blockIdx.x + (wave >> 1), forward lane half
+  // wave & 1 - with lane c on bit c of the word (bit j / 16 + j = even / odd key of pair j, see mask_pos): the word of a
+  // query row is then, bit for bit, the select mask of that row over the wave's lanes.
+  int key;
+  if constexpr (DROP) {
+    const int j = c & 15;
+    key = (2 * bx + (wave >> 1)) * 64 + 32 * (j >> 3) + 8 * ((j >> 1) & 3) + 4 * (wave & 1) + 2 * (j & 1) + (c >> 4);
+  } else {
+    key = bx * 128 + wave * 32 + c;
+  }
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
   const bool causal = d.mask_mode == 1;
   const float c2 = P.c2;
@@ -618,21 +730,20 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   f32x16 dk[2], dv[2];
   ZERO2(dk);
   ZERO2(dv);
-  const uint32_t drop_thr = P.drop_thr;
-  const float keep_scale = P.keep_scale;
-  const uint32_t skey = tmi_stream_key(((uint64_t)P.seed_hi << 32) | P.seed_lo, (uint32_t)(b * d.H + head));
-  const uint32_t khalf = (uint32_t)key >> 1, ksh = ((uint32_t)key & 1u) * 16u;
-  const uint32_t lane_mask = 0xffffu << ksh, lane_thr = drop_thr << ksh;  // this key's half of a pair hash, in place
-  auto keep_at = [&](float ra, float rb) -> bool {  // this lane's key against the query row whose mask-row key is (ra, rb)
-    const uint32_t hh = tmi_pair_hash(tmi_rowkey{__float_as_uint(ra), __float_as_uint(rb)}, khalf);
-    return ((hh >> ksh) & 0xffffu) >= drop_thr;
-  };
-  // row keys of the 64 streamed query rows: one thread each, next to the softmax constants in LDS
-  auto put_row_keys = [&](float* dst, int row0) {  // threads 0..63
-    const tmi_rowkey rk = tmi_row_key(skey, (uint32_t)(row0 + (int)threadIdx.x));
-    dst[256 + threadIdx.x] = __uint_as_float(rk.a);
-    dst[320 + threadIdx.x] = __uint_as_float(rk.b);
-  };
+  // The wave's rows of the stored mask, as 64-bit scalars: pair (rbk, e) of query tile `tile` = words of rows
+  // acc_row(e, 0) | acc_row(e, 1) of that 32-row half = the select mask of accumulator register e (scalar loads: the
+  // address is wave-uniform, the data is read-only here)
+  // acc_row(e, 1) of that 32-row half = the select mask of accumulator register e.  The 64 words of a tile are fetched by
+  // four s_load_dwordx16 issued at the END of the previous tile, just before its vmcnt(0) + barrier (scalar loads share
+  // lgkmcnt with the LDS reads and return out of order, so the first LDS wait after them drains them: the only place their
+  // latency hides is a stretch without LDS waits, and the tile seam is one), and waited for right after the barrier; a
+  // vector load of the tile after that one pulls its lines into L2 under a whole tile of work.  Inline asm because hipcc
+  // issues a scalar load and waits for it in the same breath.
+  typedef __attribute__((ext_vector_type(16))) uint32_t u32x16;
+  const uint32_t* mwave = nullptr;
+  if constexpr (DROP)
+    mwave = (P.dmask + ((((int64_t)(b * d.H + head) * P.NT) + min(2 * bx + (wave >> 1), P.NT - 1)) * 2 + (wave & 1)) * P.TQP);  // (a wave past the last key tile owns no key: any row will do)
+  const float inv_ks = DROP ? 1.0f / P.keep_scale : 1.0f;
 
   // per-tile row constants: thread t carries (which = t / 64, row = t % 64)
   // (the raw loads are combined only when they are written to LDS at the end of the iteration, so
@@ -647,8 +758,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
       x1 = stats[qi * 2 + 1];
     }
   };
+  // with dropout dS = keep_scale * (P_kept * dP - P * delta / keep_scale): the factor goes to the final store of dK
   auto make_const = [&](float x0, float x1) -> float {
-    return cwhich == 1 ? x1 : (cwhich == 3 ? lg2(x1) - x0 : x0);
+    return cwhich == 1 ? x1 : (cwhich == 3 ? lg2(x1) - x0 : (cwhich == 2 ? x0 * inv_ks : x0));
   };
 
   const LaneSrc Qs = lane_src(qb, d.q_st, Tq, wave, lane);
@@ -660,10 +772,24 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
     float x0, x1;
     load_consts(0, x0, x1);
     rowc_base[threadIdx.x] = make_const(x0, x1);
-    if (DROP && threadIdx.x < 64) put_row_keys(rowc_base, 0);
   }
+  u32x16 mk0, mk1, mk2, mk3;  // select masks of the 32-row halves: (mk0, mk1) rows 0..31, (mk2, mk3) rows 32..63; 32 SGPRs live at a time
+  auto issue_masks0 = [&](int tile) {  // first half of a tile + one dword of each line of the second half (scalar-cache warm-up)
+    const uint32_t* mt = mwave + tile * 64;
+    uint32_t t0_, t1_;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
+                 : "=&s"(mk0), "=&s"(mk1), "=&s"(t0_), "=&s"(t1_) : "s"(mt) : "memory");
+  };
+  auto issue_masks1 = [&](int tile) {
+    const uint32_t* mt = mwave + tile * 64;
+    asm volatile("s_load_dwordx16 %0, %2, 0x80\n\ts_load_dwordx16 %1, %2, 0xc0" : "=&s"(mk2), "=&s"(mk3) : "s"(mt) : "memory");
+  };
+  auto wait_masks0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk0), "+s"(mk1)::"memory"); };
+  auto wait_masks1 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk2), "+s"(mk3)::"memory"); };
+  if constexpr (DROP) issue_masks0(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (DROP) wait_masks0();
   int cur = 0;
   auto body = [&](int tile, auto edge_tag) {
     constexpr bool edge = decltype(edge_tag)::value;
@@ -671,37 +797,34 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
     const char* Oimg = Qimg + IMG;
     const float* rowc = rowc_base + cur * (NCONST * 64);
     float cn0 = 0.f, cn1 = 1.f;
+    uint32_t warm = 0;
     const bool more = tile + 1 < ntiles;
     if (more) {
       char* nx = smem + (cur ^ 1) * 2 * IMG;
       stage_tile(nx, Qs, (tile + 1) * TROWS, wave, lane);
       stage_tile(nx + IMG, Os, (tile + 1) * TROWS, wave, lane);
       load_consts((tile + 1) * TROWS, cn0, cn1);
+      if constexpr (DROP) {
+        if (tile + 2 < ntiles) warm = mwave[(tile + 2) * 64 + lane];
+      }
     }
     const int q0 = tile * TROWS;
+    // select mask of accumulator register e of 32-row half rbk
+    auto keep_of = [&](int rbk, int e) -> bool {
+      const int i = 2 * ((8 * rbk + (e & 7)));  // dword index inside the 16-dword chunk 2 rbk + (e >> 3)
+      const u32x16& v = (rbk == 0) ? ((e < 8) ? mk0 : mk1) : ((e < 8) ? mk2 : mk3);
+      const int j = i & 15;
+      return __builtin_amdgcn_inverse_ballot_w64(((uint64_t)v[j + 1] << 32) | v[j]);
+    };
 #pragma unroll
     for (int rbk = 0; rbk < 2; ++rbk) {
       f32x16 s = first_product(Qimg, 32 * rbk, kf, c, h);   // s[q][key]
       f32x16 dp = first_product(Oimg, 32 * rbk, vf, c, h);  // dp[q][key]
       f32x16 ds;
+      if constexpr (DROP) {
+        if (rbk == 1) wait_masks1();
+      }
       if constexpr (!edge) {
-        // Dropout draws: the pair hash of (query row, key >> 1) is the SAME number in the two lanes of a key pair (the even
-        // key takes its low half, the odd key the high half), so each lane computes it for half of its 16 query rows -
-        // the even lane for accumulator registers 0..7, the odd lane for 8..15 - and the pair swaps through DPP
-        // (quad_perm): 8 hashes + 16 cross-lane moves per lane instead of 16 hashes.
-        uint32_t hx[DROP ? 8 : 1];
-        if constexpr (DROP) {
-          const int odd = lane & 1;
-#pragma unroll
-          for (int jg = 0; jg < 2; ++jg) {
-            const int r = 32 * rbk + 8 * (jg + 2 * odd) + 4 * h;  // rows of registers 4 jg + 8 odd .. + 3
-            const f32x4 ra4 = *reinterpret_cast<const f32x4*>(rowc + 256 + r);
-            const f32x4 rb4 = *reinterpret_cast<const f32x4*>(rowc + 320 + r);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              hx[4 * jg + i] = tmi_pair_hash(tmi_rowkey{__float_as_uint(ra4[i]), __float_as_uint(rb4[i])}, khalf);
-          }
-        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int r = 32 * rbk + 8 * g + 4 * h;
@@ -711,22 +834,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
           for (int i = 0; i < 4; ++i) {
             const int e = 4 * g + i;
             const float pe = ex2(fmaf(s[e], c2, nM[i]));
-            if constexpr (DROP) {  // dV sees the dropped probabilities, dS the masked dP: ds = p * (mask/keep * dp - delta)
-              // registers 0..7: the even lane's hash (quad_perm [0,0,2,2]); 8..15: the odd lane's ([1,1,3,3]).  The swap is
-              // the DPP operand of the AND that cuts this lane's 16 bits out of the 32 (low half for the even key, high
-              // half - left in place, compared with the threshold shifted likewise - for the odd one): one instruction
-              // instead of move + bit-field extract.  REQUIRES a full EXEC mask: a DPP read from an inactive lane returns
-              // stale data (bound_ctrl is off), and all four lanes of a quad are active here only because nothing above
-              // this `!edge` body exits lane-divergently - keep it that way.  (s_nop: a DPP read needs two wait states after the VALU write of
-              // its source, and the hazard recogniser does not look inside asm.)
-              uint32_t cut;
-              if (e < 8)
-                asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf" : "=v"(cut) : "v"(hx[e & 7]), "v"(lane_mask));
-              else
-                asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf" : "=v"(cut) : "v"(hx[e & 7]), "v"(lane_mask));
-              const bool keep = cut >= lane_thr;
-              s[e] = keep ? pe : 0.f;
-              ds[e] = pe * fmaf(dp[e], keep ? keep_scale : 0.f, -dl[i]);  // (select on the constant: one op fewer than on the product)
+            if constexpr (DROP) {  // dV sees the dropped probabilities; dS / keep_scale = P_kept * dP - P * (delta / keep_scale)
+              s[e] = keep_of(rbk, e) ? pe : 0.f;  // v_cndmask on a scalar pair
+              ds[e] = fmaf(s[e], dp[e], -(pe * dl[i]));
             } else {
               s[e] = pe;
               ds[e] = pe * (dp[e] - dl[i]);
@@ -742,26 +852,32 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
           if (causal && key <= qi) x = x + MASKED2;
           const float pe = (qi < Tq) ? ex2(x - rowc[r]) * rowc[64 + r] : 0.f;
           if constexpr (DROP) {
-            const bool keep = keep_at(rowc[256 + r], rowc[320 + r]);
-            s[e] = keep ? pe : 0.f;
-            ds[e] = pe * ((keep ? dp[e] * keep_scale : 0.f) - rowc[128 + r]);
+            s[e] = keep_of(rbk, e) ? pe : 0.f;
+            ds[e] = fmaf(s[e], dp[e], -(pe * rowc[128 + r]));
           } else {
             s[e] = pe;
             ds[e] = pe * (dp[e] - rowc[128 + r]);
           }
         }
       }
+      if constexpr (DROP) {
+        // second half's masks: issued once the first half's are spent (same registers), a scalar-cache hit by now, in flight
+        // under the 16 MFMAs below and the next 8; waited for where that half's arithmetic starts
+        if (rbk == 0) issue_masks1(tile);
+      }
       second_product(Oimg, 32 * rbk, s, dv, lane);   // dVt[d][key] += sum_q dO[q][d] P[q][key]
       second_product(Qimg, 32 * rbk, ds, dk, lane);  // dKt[d][key] += sum_q Q[q][d] dS[q][key]
     }
-    if (more) {
-      rowc_base[(cur ^ 1) * (NCONST * 64) + threadIdx.x] = make_const(cn0, cn1);
-      if (DROP && threadIdx.x < 64) put_row_keys(rowc_base + (cur ^ 1) * (NCONST * 64), (tile + 1) * TROWS);
-    }
+    if (more) rowc_base[(cur ^ 1) * (NCONST * 64) + threadIdx.x] = make_const(cn0, cn1);
     PIN(cn0);  // the compiler's wait for these two loads belongs here, on every path, not after the
     PIN(cn1);  // next iteration's DMA issue
+    PIN(warm);
+    if constexpr (DROP) {
+      if (more) issue_masks0(tile + 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (DROP) wait_masks0();
     cur ^= 1;
   };
   const int nfast = causal ? 0 : Tq / TROWS;
@@ -770,7 +886,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   for (; tile < ntiles; ++tile) body(tile, std::true_type{});
   bf16_t* dkb = reinterpret_cast<bf16_t*>(d.dk) + b * d.dk_sb + head * HD;
   bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
-  store_owner(dk, dkb, d.dk_st, key, Tk, h, P.sscale);
+  store_owner(dk, dkb, d.dk_st, key, Tk, h, DROP ? P.sscale * P.keep_scale : P.sscale);
   store_owner(dv, dvb, d.dv_st, key, Tk, h, DROP ? P.keep_scale : 1.0f);
 }
 
@@ -778,19 +894,27 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 inline bool ok_mat(const void* p, int64_t sb, int64_t st) { return p && al16(p) && sb % 8 == 0 && st % 8 == 0; }
 
 #ifndef TMI_ATTN_DROP_OCC
-#define TMI_ATTN_DROP_OCC 3
+#define TMI_ATTN_DROP_OCC 2
 #endif
 #ifndef TMI_ATTN_DQ_DROP_OCC
 #define TMI_ATTN_DQ_DROP_OCC 2
 #endif
-// workgroups per CU of the dropout variants (the hash needs registers: the dQ kernel spills at 3 per CU)
+// workgroups per CU of the dropout variants (the forward's generator and mask packing need registers: 3 per CU spills, and
+// measured 124.5 us against 122.9 at 2 per CU on the encoder layer; the dQ kernel spills at 3 per CU too)
 constexpr int DROP_OCC = TMI_ATTN_DROP_OCC, DQ_DROP_OCC = TMI_ATTN_DQ_DROP_OCC;
+
+int64_t mask_tiles(int64_t Tk) { return (Tk + TROWS - 1) / TROWS; }
+int64_t mask_rows(int64_t Tq) { return (Tq + 127) / 128 * 128; }
 
 void set_dropout(AttnP& P) {
   P.drop_thr = tmi_drop_thr(P.d.dropout_p);
   P.keep_scale = tmi_keep_scale(P.drop_thr);
   P.seed_lo = (uint32_t)P.d.dropout_seed;
   P.seed_hi = (uint32_t)(P.d.dropout_seed >> 32);
+  P.tm1 = (((uint32_t)((int32_t)P.drop_thr - 32768 - 1)) & 0xffffu) * 0x10001u;
+  P.dmask = reinterpret_cast<uint32_t*>(P.d.drop_mask);
+  P.NT = (int)mask_tiles(P.d.Tk);
+  P.TQP = (int)mask_rows(P.d.Tq);
 }
 
 // key split of the forward / dQ passes: a single query tile against >= 8 key tiles with no causal mask, when the caller
@@ -811,10 +935,26 @@ int pick_ksplit(const tmi_attn_desc& d) {
   return ks;
 }
 
+// launch grid of `gx` blocks per (batch, head): XCD-aware 1-D form when the pairs divide over the 8 XCDs and there is more
+// than one block per pair to share rows (TMI_ATTN_XCD=0 switches it off)
+dim3 pick_grid(AttnP& P, unsigned gx) {
+  static const int on = [] { const char* e = getenv("TMI_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  const int64_t bh = P.d.B * P.d.H;
+  if (on && gx > 1 && bh % 8 == 0 && bh * gx < (1ll << 31)) {
+    P.gx = (int)gx;
+    return dim3((unsigned)(bh * gx), 1, 1);
+  }
+  P.gx = 0;
+  return dim3(gx, (unsigned)P.d.H, (unsigned)P.d.B);
+}
+
 int check_common(const tmi_attn_desc& d) {
   if (d.B <= 0 || d.H <= 0 || d.Tq <= 0 || d.Tk <= 0 || d.B > 65535 || d.H > 65535 ||
       (d.mask_mode != 0 && d.mask_mode != 1) || !d.stats || d.score_scale < 0.f || !(d.dropout_p >= 0.f && tmi_drop_ok(d.dropout_p)) ||
       (d.dropout_p > 0.f && d.Tk > TMI_DROP_MAX_COLS))
+    return 0;
+  if (d.dropout_p > 0.f && tmi_drop_thr(d.dropout_p) > 0 &&
+      (!d.drop_mask || !al16(d.drop_mask) || d.drop_mask_bytes < tmi_attn_dropmask_bytes(d.B, d.H, d.Tq, d.Tk)))
     return 0;
   return ok_mat(d.q, d.q_sb, d.q_st) && ok_mat(d.k, d.k_sb, d.k_st) && ok_mat(d.v, d.v_sb, d.v_st) &&
          ok_mat(d.o, d.o_sb, d.o_st);
@@ -822,13 +962,18 @@ int check_common(const tmi_attn_desc& d) {
 
 }  // namespace
 
+extern "C" int64_t tmi_attn_dropmask_bytes(int64_t B, int64_t H, int64_t Tq, int64_t Tk) {
+  if (B <= 0 || H <= 0 || Tq <= 0 || Tk <= 0) return 0;
+  return B * H * mask_tiles(Tk) * 2 * mask_rows(Tq) * 4;
+}
+
 extern "C" int64_t tmi_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tq) {
   return Tq <= 128 ? B * H * 8 * Tq * (HD + 2) * 4 : 0;
 }
 
 extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   if (!dp || !check_common(*dp)) {
-    tmi_set_error("tmi_attn_fwd: bad argument (16-byte aligned bf16 operands, strides multiple of 8)");
+    tmi_set_error("tmi_attn_fwd: bad argument (16-byte aligned bf16 operands, strides multiple of 8; dropout_p > 0 needs drop_mask of tmi_attn_dropmask_bytes)");
     return TMI_ERR_INVALID;
   }
   AttnP P;
@@ -839,9 +984,7 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   set_dropout(P);
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
-  static const int adbg = [] { const char* e = getenv("TMI_ATTN_DBG"); return e ? atoi(e) : 0; }();
-  P.dbg = adbg;
-  dim3 grid((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
+  dim3 grid = pick_grid(P, (unsigned)((dp->Tq + 127) / 128 * P.ksplit));
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int focc = [] { const char* e = getenv("TMI_ATTN_FWD_OCC"); return e ? atoi(e) : 0; }();
   if (P.drop_thr) {
@@ -853,16 +996,15 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
     if (focc == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), grid, dim3(256), 4 * IMG, hs, P);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 5>), grid, dim3(256), 4 * IMG, hs, P);
   } else {
+#ifdef TMI_ATTN_EXPERIMENTS  // ablation builds of the forward (diagnostics; not in the shipped library)
     static const int abl = [] { const char* e = getenv("TMI_ATTN_ABL"); return e ? atoi(e) : 0; }();
     if (abl == 1) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 1>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 2) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 2>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 3) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 3>), grid, dim3(256), 4 * IMG, hs, P);
     else if (abl == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 3, 4>), grid, dim3(256), 4 * IMG, hs, P);
-    else {
-      static const int ldsdbg = [] { const char* e = getenv("TMI_ATTN_LDS"); return e ? atoi(e) : 0; }();  // diagnostics: co-residency
-      if (ldsdbg > 4 * IMG) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsdbg);
-      hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), ldsdbg > 4 * IMG ? ldsdbg : 4 * IMG, hs, P);
-    }
+    else
+#endif
+    hipLaunchKernelGGL((attn_fwd_kernel<false, 3>), grid, dim3(256), 4 * IMG, hs, P);
   }
   if (P.ksplit > 1) {
     const int64_t rows = dp->B * dp->H * dp->Tq;
@@ -894,7 +1036,7 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
   if (do_dq) {
-  dim3 gq((unsigned)((dp->Tq + 127) / 128 * P.ksplit), (unsigned)dp->H, (unsigned)dp->B);
+  dim3 gq = pick_grid(P, (unsigned)((dp->Tq + 127) / 128 * P.ksplit));
   static const int qocc = [] { const char* e = getenv("TMI_ATTN_DQ_OCC"); return e ? atoi(e) : 0; }();
   if (P.drop_thr) {
     if (qocc == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 3>), gq, dim3(256), 4 * IMG, s, P);
@@ -917,7 +1059,7 @@ extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
   }
   if (!do_dkv) return TMI_OK;
   P.ksplit = 1;
-  dim3 gk((unsigned)((dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+  dim3 gk = pick_grid(P, (unsigned)((dp->Tk + 127) / 128));
   static const int kocc = [] { const char* e = getenv("TMI_ATTN_DKV_OCC"); return e ? atoi(e) : 0; }();
   const size_t klds = 4 * IMG + 2 * NCONST * 64 * sizeof(float);
   if (P.drop_thr) {

@@ -123,6 +123,33 @@ __host__ __device__ __forceinline__ bool tmi_keep(uint32_t stream_key, uint32_t 
   return r >= thr;
 }
 
+// ---- attention-probability dropout (W:160): the generator of the flash kernels.  Only tmi_attn_fwd evaluates it (the
+// backward kernels read the keep bits the forward stored, 1 bit per score), so it is shaped for that kernel's lane: one
+// evaluation serves the FOUR consecutive keys 4cq .. 4cq+3 that a lane holds in one accumulator quad -
+//   x = ra ^ cq;  h = mul24(x, 0x9E3779);  h ^= (h >> 15) ^ rb;  ha = mul24(h, 0x85EBCB);  hb = mul24(h, 0xC2B2AE)
+// (six full-rate VALU instructions per four scores; (ra, rb) = tmi_row_key of (stream b*H + head, query row)).  Draws: key
+// 4cq + {0, 1, 2, 3} = {low half of ha, high half of ha, low half of hb, high half of hb}, read as SIGNED 16-bit numbers;
+// a probability is kept when its draw >= thr - 32768 (thr = round(p * 65536), the same rate and keep scale as the flat
+// generator above).  The signed form is what lets the kernel test two draws with one v_pk_sub_i16 (saturating) + one
+// v_pk_ashrrev_i16 and apply the result to a packed bf16 pair.  Restated in oracle/dropout.py (keep_attention).
+struct tmi_quad { uint32_t a, b; };
+__host__ __device__ __forceinline__ tmi_quad tmi_quad_hash_x(uint32_t x, uint32_t rb) {  // x = ra ^ cq
+  uint32_t h = tmi_mul24(x, 0x9E3779u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  h = __builtin_amdgcn_bitop3_b32(h, h >> 15, rb, 0x96);
+#else
+  h = h ^ (h >> 15) ^ rb;
+#endif
+  return tmi_quad{tmi_mul24(h, 0x85EBCBu), tmi_mul24(h, 0xC2B2AEu)};
+}
+__host__ __device__ __forceinline__ tmi_quad tmi_quad_hash(tmi_rowkey rk, uint32_t cq) { return tmi_quad_hash_x(rk.a ^ cq, rk.b); }
+__host__ __device__ __forceinline__ bool tmi_keep_attn(uint32_t stream_key, uint32_t row, uint32_t col, uint32_t thr) {
+  const tmi_quad hq = tmi_quad_hash(tmi_row_key(stream_key, row), col >> 2);
+  const uint32_t w = (col & 2) ? hq.b : hq.a;
+  const int32_t d = (int32_t)(int16_t)((col & 1) ? (w >> 16) : (w & 0xffffu));
+  return d >= (int32_t)thr - 32768;
+}
+
 // dropout term of a GEMM epilogue (tmi_gemm_desc.dropout_p): 8 consecutive columns n .. n+7 (n even) of output row m
 __device__ __forceinline__ void tmi_drop8(float (&v)[8], int64_t m, int64_t n, uint32_t key, uint32_t thr, float scale) {
   const tmi_rowkey rk = tmi_row_key(key, (uint32_t)m);

@@ -331,18 +331,34 @@ def _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale=1.0):
     return d
 
 
-def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0, dropout_p=0.0, dropout_seed=0):
+def attn_dropmask(device, B, H, Tq, Tk):
+    """Buffer for the keep bits of one attention call with dropout (tmi_attn_desc.drop_mask): written by the forward, read by
+    the backward of the same call, so the caller keeps one per dropout site from forward to backward."""
+    return torch.empty(int(lib().tmi_attn_dropmask_bytes(B, H, Tq, Tk)), dtype=torch.uint8, device=device)
+
+
+def _set_dropout(d, dropout_p, dropout_seed, drop_mask):
+    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    if dropout_p > 0.0:
+        if drop_mask is None:
+            raise ValueError("attention dropout needs a drop_mask buffer (ops.attn_dropmask): the forward stores the mask, "
+                             "the backward reads it")
+        d.drop_mask, d.drop_mask_bytes = drop_mask.data_ptr(), drop_mask.numel() * drop_mask.element_size()
+
+
+def attn_fwd(q, k, v, o, stats, B, H, Tq, Tk, mask_mode=0, score_scale=1.0, dropout_p=0.0, dropout_seed=0, drop_mask=None):
     with _probe("attention", 4.0 * B * H * Tq * Tk * 64):
         d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
-        d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+        _set_dropout(d, dropout_p, dropout_seed, drop_mask)
         check(lib().tmi_attn_fwd(C.byref(d), stream()), "tmi_attn_fwd")
 
 
 def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0, dq_scale=1.0, score_scale=1.0,
-             dropout_p=0.0, dropout_seed=0, passes=0):
-    """``passes``: 0 both, 1 the dQ pass (fills ``delta``), 2 the dK/dV pass (needs ``delta`` from pass 1)."""
+             dropout_p=0.0, dropout_seed=0, passes=0, drop_mask=None):
+    """``passes``: 0 both, 1 the dQ pass (fills ``delta``), 2 the dK/dV pass (needs ``delta`` from pass 1).
+    ``drop_mask``: the buffer the forward of this call filled (dropout_p > 0)."""
     d = _attn_desc(q, k, v, o, stats, B, H, Tq, Tk, mask_mode, score_scale)
-    d.dropout_p, d.dropout_seed = dropout_p, dropout_seed
+    _set_dropout(d, dropout_p, dropout_seed, drop_mask)
     d.bwd_passes = passes
     for name, field, (t, off, sb, st) in (("d_o", "do", do), ("dq", "dq", dq), ("dk", "dk", dk), ("dv", "dv", dv)):
         setattr(d, name, t.data_ptr() + off * t.element_size())

@@ -19,10 +19,11 @@ def run(name, Tq, Tk, mask, iters=20):
     o = torch.empty_like(q); dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
     stats = torch.empty(B, H, Tq, 2, device=dev); delta = torch.empty(B, H, Tq, device=dev)
     sc = HD ** -0.5
+    dm = ops.attn_dropmask(dev, B, H, Tq, Tk) if DROP > 0 else None
     Q = (q, 0, Tq * D, D); K = (k, 0, Tk * D, D); V = (v, 0, Tk * D, D); O = (o, 0, Tq * D, D)
-    fwd = lambda: ops.attn_fwd(Q, K, V, O, stats, B, H, Tq, Tk, mask, score_scale=sc, dropout_p=DROP, dropout_seed=77)
+    fwd = lambda: ops.attn_fwd(Q, K, V, O, stats, B, H, Tq, Tk, mask, score_scale=sc, dropout_p=DROP, dropout_seed=77, drop_mask=dm)
     bwd = lambda: ops.attn_bwd(Q, K, V, O, stats, (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D),
-                               (dv, 0, Tk * D, D), delta, B, H, Tq, Tk, mask, score_scale=sc, dropout_p=DROP, dropout_seed=77)
+                               (dv, 0, Tk * D, D), delta, B, H, Tq, Tk, mask, score_scale=sc, dropout_p=DROP, dropout_seed=77, drop_mask=dm)
     for fn, label, nprod in ((fwd, "fwd", 2), (bwd, "bwd(dq+dkv)", 7)):
         for _ in range(3):
             fn()
