@@ -459,6 +459,7 @@ def main():
                     help="form of the gradient exchange (N > 1): dist.DataParallelStrategy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-plan", action="store_true", help="issue every step from Python instead of replaying a launch plan (tethys_speech_amd/plan.py)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of timed CPU work for the first thread setting")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -509,6 +510,14 @@ def main():
             # pipelined: the next call is another step (the decoder layers' Adam slice runs under its encoder forward); the
             # timed region ends with a device-wide synchronize, which covers the last one
             return train.distributed_train_step(strategy, model, batch, opt, pipelined=True)
+        # the same step through a launch plan (one replica: recorded once, then replayed from one C call; train.planned_step)
+        pstep = train.planned_step(strategy, model, opt, "whisper", pipelined=True)
+
+        def timed_step():
+            batch = next(it)
+            if batch[0].shape[0] != args.batch_size:
+                raise RuntimeError(f"rank {rank} drew {batch[0].shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
+            return pstep(*batch)
         c = model.config
         metric = f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)"
         workload = (f"whisper-{args.model_type}-ref (reference '{args.model_type}': {c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, "
@@ -542,6 +551,14 @@ def main():
                 raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
             # (pipelined: see the Whisper step above)
             return train.wav2vec2_train_step(strategy, model, audio, negs[ctr[0] % len(negs)], opt, pipelined=True)
+        pstep = train.planned_step(strategy, model, opt, "wav2vec2", pipelined=True)
+
+        def timed_step():
+            ctr[0] += 1
+            audio = next(it)
+            if audio.shape[0] != args.batch_size:
+                raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
+            return pstep(audio, negs[ctr[0] % len(negs)])
         metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
         workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
         gf_sample = W2V_GF_PER_SAMPLE.get(size)
@@ -559,13 +576,26 @@ def main():
             def one_step():  # noqa: F811
                 ctr[0] += 1
                 return train.single_train_step(model, next(it), negs_t[ctr[0] % len(negs_t)], opt)
+            pstep = train.planned_step(strategy, model, opt, "single")
+
+            def timed_step():  # noqa: F811
+                ctr[0] += 1
+                return pstep(next(it), negs_t[ctr[0] % len(negs_t)])
             metric = "audio-seconds/sec/node (whisper_single.py = Wav2Vec2-base single-device step, 5 s clips)"
             workload = f"speech_jobs/whisper_single.py step (S:): wav2vec2-base, batch {args.batch_size}, 5 s clips [80000]"
             gf_sample = None
         tag = f"wav2vec2_{size}"
 
     log(f"model ready ({model.arena.n_params} params), warming up {args.warmup} steps")
-    dt, last_loss, host_ms = timed_region(one_step, args, strategy, dev, world)
+    if args.no_plan:
+        timed_step, pstep = one_step, one_step
+        pstep.planned = None
+    dt, last_loss, host_ms = timed_region(timed_step, args, strategy, dev, world)
+    plan_note = None
+    if getattr(pstep, "planned", None) is not None:
+        pl = [v["plan"] for v in pstep.planned._by_sig.values() if v.get("plan") is not None]
+        plan_note = {"replayed_steps": pstep.planned.replays, "launches": [p_.launches for p_ in pl], "nodes": [p_.nodes for p_ in pl]}
+        log(f"launch plan: {plan_note}")
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step, loss {last_loss:.4f}")
 
     multi = None
@@ -586,6 +616,7 @@ def main():
                        "dropout": drop_note, "grad_exchange_dtype": args.grad_dtype if world > 1 else None,
                        "exchange": args.exchange if world > 1 else None,
                        "host_enqueue_ms_per_step": host_ms,
+                       "launch_plan": plan_note,
                        "step_tflops": gf_sample * gb * args.steps / dt / 1e3 if gf_sample else None},
         }
         if multi is not None:

@@ -163,6 +163,37 @@ int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int
                          int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Launch plans: record the launches of one training step once, replay them from ONE call.
+ * Replaces what `@tf.function` gives the reference's step (W:818-819: the first call traces the step, every later call
+ * replays the traced graph with no Python between its ops).  While a plan records (tmi_plan_begin .. tmi_plan_end, on the
+ * calling thread) every launching entry point of this header appends itself, with its arguments copied by value, to the
+ * plan and then runs as usual: the recorded step is a real step.  tmi_plan_replay issues the recorded calls in order -
+ * the same entry points, argument checks and dispatch rules, no host code in between - adding `seed_delta` to every
+ * recorded dropout seed (site seeds are base + step * K + site * K': pass (step_now - step_recorded) * K mod 2^64) and
+ * `step_delta` to the `step` argument of tmi_adam_step / _rows / _segments.
+ * Ordering between streams is part of the plan: the host reports each event record / stream wait it makes while recording
+ * (tmi_plan_note_event_record / tmi_plan_note_stream_wait, raw hipEvent_t / hipStream_t handles that must outlive the
+ * plan) and the replay repeats them with hipEventRecord / hipStreamWaitEvent.  tmi_plan_note_callback records a host
+ * function called in sequence (what a step does between launches that is not this library's: an RCCL collective).
+ * Memory operations of a step go through tmi_memset_async / tmi_memset2d_async / tmi_memcpy_async (device to device)
+ * so that they are recorded too.  tmi_plan_size: what = 0 nodes, 1 launches.  One recorder per thread; a plan is
+ * replayed by one thread at a time.
+ */
+typedef struct tmi_plan tmi_plan;
+int tmi_plan_create(tmi_plan** out);
+int tmi_plan_destroy(tmi_plan* plan);
+int tmi_plan_begin(tmi_plan* plan);
+int tmi_plan_end(tmi_plan* plan);
+int tmi_plan_replay(tmi_plan* plan, uint64_t seed_delta, int64_t step_delta);
+int64_t tmi_plan_size(const tmi_plan* plan, int32_t what);
+int tmi_plan_note_event_record(void* event, void* stream);
+int tmi_plan_note_stream_wait(void* stream, void* event);
+int tmi_plan_note_callback(void (*fn)(void));
+int tmi_memset_async(void* dst, int32_t value, int64_t bytes, void* stream);
+int tmi_memset2d_async(void* dst, int64_t pitch_bytes, int32_t value, int64_t width_bytes, int64_t rows, void* stream);
+int tmi_memcpy_async(void* dst, const void* src, int64_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Materialised-score softmax (fp32 "parity mode" attention, the reference's own graph
  * shape: W:147-167).  s[rows, Tk] in place; row r belongs to query i = r % Tq.
  * mask_mode 0: none.  mask_mode 1: the reference decoder's additive mask

@@ -63,6 +63,18 @@ SIGNATURES = {
     "tmi_abi_version": (c_i32, []),
     "tmi_last_error": (C.c_char_p, []),
     "tmi_set_deterministic": (c_i32, [c_i32]),
+    "tmi_plan_create": (c_i32, [C.POINTER(c_vp)]),
+    "tmi_plan_destroy": (c_i32, [c_vp]),
+    "tmi_plan_begin": (c_i32, [c_vp]),
+    "tmi_plan_end": (c_i32, [c_vp]),
+    "tmi_plan_replay": (c_i32, [c_vp, C.c_uint64, c_i64]),
+    "tmi_plan_size": (c_i64, [c_vp, c_i32]),
+    "tmi_plan_note_event_record": (c_i32, [c_vp, c_vp]),
+    "tmi_plan_note_stream_wait": (c_i32, [c_vp, c_vp]),
+    "tmi_plan_note_callback": (c_i32, [c_vp]),
+    "tmi_memset_async": (c_i32, [c_vp, c_i32, c_i64, c_vp]),
+    "tmi_memset2d_async": (c_i32, [c_vp, c_i64, c_i32, c_i64, c_i64, c_vp]),
+    "tmi_memcpy_async": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "tmi_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "tmi_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
     "tmi_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
@@ -121,7 +133,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 _lib = None
 
 

@@ -331,7 +331,21 @@ __global__ __launch_bounds__(256) void adam_segments_kernel(float* __restrict__ 
 
 }  // namespace
 
+static int tmi_adam_step_segments_impl(float* p, float* g, float* m, float* v, const int64_t* chunks, int64_t nchunks,
+                                      const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr, float beta1, float beta2,
+                                      float eps, int32_t step, int32_t eps_mode, float weight_decay, float gscale,
+                                      void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream);
 extern "C" int tmi_adam_step_segments(float* p, float* g, float* m, float* v, const int64_t* chunks, int64_t nchunks,
+                                      const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr, float beta1, float beta2,
+                                      float eps, int32_t step, int32_t eps_mode, float weight_decay, float gscale,
+                                      void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_adam_step_segments(p, g, m, v, chunks, nchunks, sumsq, nseg, clip_global, clip_each, lr, beta1, beta2, eps, (int32_t)(step + tmi_plan_step_delta()), eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, max_blocks, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_adam_step_segments_impl(p, g, m, v, chunks, nchunks, sumsq, nseg, clip_global, clip_each, lr, beta1, beta2, eps, step, eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, max_blocks, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_adam_step_segments_impl(float* p, float* g, float* m, float* v, const int64_t* chunks, int64_t nchunks,
                                       const float* sumsq, int64_t nseg, float clip_global, float clip_each, float lr, float beta1, float beta2,
                                       float eps, int32_t step, int32_t eps_mode, float weight_decay, float gscale,
                                       void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream) {
@@ -365,7 +379,21 @@ extern "C" int tmi_adam_step_segments(float* p, float* g, float* m, float* v, co
   return tmi_check_launch("tmi_adam_step_segments");
 }
 
+static int tmi_adam_step_rows_impl(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
+                                  unsigned char* active, float lr, float beta1, float beta2, float eps, int32_t step,
+                                  int32_t eps_mode, float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
+                                  void* stream);
 extern "C" int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
+                                  unsigned char* active, float lr, float beta1, float beta2, float eps, int32_t step,
+                                  int32_t eps_mode, float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
+                                  void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_adam_step_rows(p, g, m, v, nrows, row_len, active, lr, beta1, beta2, eps, (int32_t)(step + tmi_plan_step_delta()), eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_adam_step_rows_impl(p, g, m, v, nrows, row_len, active, lr, beta1, beta2, eps, step, eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_adam_step_rows_impl(float* p, float* g, float* m, float* v, int64_t nrows, int64_t row_len,
                                   unsigned char* active, float lr, float beta1, float beta2, float eps, int32_t step,
                                   int32_t eps_mode, float weight_decay, float gscale, void* bf16_mirror, int32_t zero_grad,
                                   void* stream) {
@@ -397,7 +425,19 @@ extern "C" int tmi_adam_step_rows(float* p, float* g, float* m, float* v, int64_
   return tmi_check_launch("tmi_adam_step_rows");
 }
 
+static int tmi_adam_step_impl(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int32_t step, int32_t eps_mode, float weight_decay,
+                             float gscale, void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream);
 extern "C" int tmi_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, int32_t step, int32_t eps_mode, float weight_decay,
+                             float gscale, void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_adam_step(p, g, m, v, n, lr, beta1, beta2, eps, (int32_t)(step + tmi_plan_step_delta()), eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, max_blocks, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, step, eps_mode, weight_decay, gscale, bf16_mirror, zero_grad, max_blocks, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_adam_step_impl(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, int32_t step, int32_t eps_mode, float weight_decay,
                              float gscale, void* bf16_mirror, int32_t zero_grad, int32_t max_blocks, void* stream) {
   if (!p || !g || !m || !v || n <= 0 || step <= 0 || (eps_mode != 0 && eps_mode != 1) || !al16(p) || !al16(g) ||
@@ -457,7 +497,19 @@ extern "C" int tmi_adam_scalars(float lr, float beta1, float beta2, int32_t step
 // the same update with the step-dependent scalars read from DEVICE memory (dev_scalars[3], filled from
 // tmi_adam_scalars before each replay): the launch itself carries nothing that changes from step to
 // step, so it can sit in a captured HIP graph
+static int tmi_adam_step_dev_impl(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                                 float eps, const float* dev_scalars, int32_t eps_mode, float gscale, void* bf16_mirror,
+                                 void* stream);
 extern "C" int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                                 float eps, const float* dev_scalars, int32_t eps_mode, float gscale, void* bf16_mirror,
+                                 void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_adam_step_dev(p, g, m, v, n, beta1, beta2, eps, dev_scalars, eps_mode, gscale, bf16_mirror, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_adam_step_dev_impl(p, g, m, v, n, beta1, beta2, eps, dev_scalars, eps_mode, gscale, bf16_mirror, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_adam_step_dev_impl(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
                                  float eps, const float* dev_scalars, int32_t eps_mode, float gscale, void* bf16_mirror,
                                  void* stream) {
   if (!p || !g || !m || !v || !dev_scalars || n <= 0 || (eps_mode != 0 && eps_mode != 1) || !al16(p) || !al16(g) ||
@@ -474,7 +526,17 @@ extern "C" int tmi_adam_step_dev(float* p, const float* g, float* m, float* v, i
   return tmi_check_launch("tmi_adam_step_dev");
 }
 
+static int tmi_cast_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             void* stream);
 extern "C" int tmi_cast_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols,
+                             void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_cast_bf16(src, lds_, dst, ldd, rows, cols, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_cast_bf16_impl(src, lds_, dst, ldd, rows, cols, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_cast_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows, int64_t cols,
                              void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < cols) {
     tmi_set_error("tmi_cast_bf16: bad argument");
@@ -545,7 +607,15 @@ __global__ __launch_bounds__(256) void grad_unpack_kernel(const TS* __restrict__
   }
 }
 
+static int tmi_grad_pack_impl(const float* src, void* dst, int64_t n, float scale, void* stream);
 extern "C" int tmi_grad_pack(const float* src, void* dst, int64_t n, float scale, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_grad_pack(src, dst, n, scale, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_grad_pack_impl(src, dst, n, scale, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_grad_pack_impl(const float* src, void* dst, int64_t n, float scale, void* stream) {
   if (!src || !dst || n <= 0) {
     tmi_set_error("tmi_grad_pack: bad argument");
     return TMI_ERR_INVALID;
@@ -558,7 +628,17 @@ extern "C" int tmi_grad_pack(const float* src, void* dst, int64_t n, float scale
   return tmi_check_launch("tmi_grad_pack");
 }
 
+static int tmi_grad_unpack_impl(const void* src, int32_t src_dtype, int64_t nparts, int64_t part_stride, float* dst,
+                               int64_t n, float scale, void* stream);
 extern "C" int tmi_grad_unpack(const void* src, int32_t src_dtype, int64_t nparts, int64_t part_stride, float* dst,
+                               int64_t n, float scale, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_grad_unpack(src, src_dtype, nparts, part_stride, dst, n, scale, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_grad_unpack_impl(src, src_dtype, nparts, part_stride, dst, n, scale, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_grad_unpack_impl(const void* src, int32_t src_dtype, int64_t nparts, int64_t part_stride, float* dst,
                                int64_t n, float scale, void* stream) {
   if (!src || !dst || n <= 0 || nparts <= 0 || (nparts > 1 && part_stride < n) || (src_dtype != TMI_F32 && src_dtype != TMI_BF16)) {
     tmi_set_error("tmi_grad_unpack: bad argument");
@@ -577,7 +657,17 @@ extern "C" int tmi_grad_unpack(const void* src, int32_t src_dtype, int64_t npart
   return tmi_check_launch("tmi_grad_unpack");
 }
 
+static int tmi_transpose_cast_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
+                                       int64_t cols, void* stream);
 extern "C" int tmi_transpose_cast_bf16(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
+                                       int64_t cols, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_transpose_cast_bf16(src, lds_, dst, ldd, rows, cols, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_transpose_cast_bf16_impl(src, lds_, dst, ldd, rows, cols, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_transpose_cast_bf16_impl(const float* src, int64_t lds_, void* dst, int64_t ldd, int64_t rows,
                                        int64_t cols, void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || lds_ < cols || ldd < rows || (cols + 63) / 64 > 65535 * 32) {
     tmi_set_error("tmi_transpose_cast_bf16: bad argument");
@@ -593,7 +683,17 @@ extern "C" int tmi_transpose_cast_bf16(const float* src, int64_t lds_, void* dst
   return tmi_check_launch("tmi_transpose_cast_bf16");
 }
 
+static int tmi_feat_to_channels_last_impl(const float* feats, void* out, int64_t B, int64_t C, int64_t T,
+                                         int64_t pad_left, int64_t pad_right, int32_t dtype, void* stream);
 extern "C" int tmi_feat_to_channels_last(const float* feats, void* out, int64_t B, int64_t C, int64_t T,
+                                         int64_t pad_left, int64_t pad_right, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_feat_to_channels_last(feats, out, B, C, T, pad_left, pad_right, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_feat_to_channels_last_impl(feats, out, B, C, T, pad_left, pad_right, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_feat_to_channels_last_impl(const float* feats, void* out, int64_t B, int64_t C, int64_t T,
                                          int64_t pad_left, int64_t pad_right, int32_t dtype, void* stream) {
   if (!feats || !out || B <= 0 || C <= 0 || C > 256 || T <= 0 || pad_left < 0 || pad_right < 0 || B > 65535) {
     tmi_set_error("tmi_feat_to_channels_last: bad argument (C <= 256)");
@@ -614,7 +714,15 @@ extern "C" int tmi_feat_to_channels_last(const float* feats, void* out, int64_t 
   return tmi_check_launch("tmi_feat_to_channels_last");
 }
 
+static int tmi_sumsq_impl(const float* x, float* out, int64_t n, int32_t accumulate, void* stream);
 extern "C" int tmi_sumsq(const float* x, float* out, int64_t n, int32_t accumulate, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_sumsq(x, out, n, accumulate, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_sumsq_impl(x, out, n, accumulate, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_sumsq_impl(const float* x, float* out, int64_t n, int32_t accumulate, void* stream) {
   if (!x || !out || n <= 0) {
     tmi_set_error("tmi_sumsq: bad argument");
     return TMI_ERR_INVALID;
@@ -659,7 +767,19 @@ __global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ s
 }
 }  // namespace
 
+static int tmi_logmel_from_spectrum_impl(const float* spec, int64_t ld_spec, const float* mel, float* out, int64_t frames,
+                                        int32_t n_bins, int32_t n_mels, float eps, int32_t channels_first, int64_t ld_out,
+                                        void* stream);
 extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, const float* mel, float* out, int64_t frames,
+                                        int32_t n_bins, int32_t n_mels, float eps, int32_t channels_first, int64_t ld_out,
+                                        void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_logmel_from_spectrum(spec, ld_spec, mel, out, frames, n_bins, n_mels, eps, channels_first, ld_out, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_logmel_from_spectrum_impl(spec, ld_spec, mel, out, frames, n_bins, n_mels, eps, channels_first, ld_out, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_logmel_from_spectrum_impl(const float* spec, int64_t ld_spec, const float* mel, float* out, int64_t frames,
                                         int32_t n_bins, int32_t n_mels, float eps, int32_t channels_first, int64_t ld_out,
                                         void* stream) {
   if (!spec || !mel || !out || frames <= 0 || n_bins <= 0 || n_mels <= 0 || ld_spec < 2 * (int64_t)n_bins ||
@@ -676,7 +796,17 @@ extern "C" int tmi_logmel_from_spectrum(const float* spec, int64_t ld_spec, cons
 
 // Dropout over a [rows, cols] tensor (cols even), optionally added to a residual: the forward of W:205 / W:342 /
 // W:411 and, applied to the incoming gradient with the same seed, their backward.  In-place (out == in) is fine.
+static int tmi_dropout_impl(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
+                           int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream);
 extern "C" int tmi_dropout(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
+                           int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_dropout(in, ld_in, resid, ld_res, out, ld_out, rows, cols, p, seed + tmi_plan_seed_delta(), dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_dropout_impl(in, ld_in, resid, ld_res, out, ld_out, rows, cols, p, seed, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_dropout_impl(const void* in, int64_t ld_in, const void* resid, int64_t ld_res, void* out, int64_t ld_out,
                            int64_t rows, int64_t cols, float p, uint64_t seed, int32_t dtype, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0 || (cols & 1) || cols > TMI_DROP_MAX_COLS || ld_in < cols || ld_out < cols || (resid && ld_res < cols) ||
       !(p >= 0.f && tmi_drop_ok(p))) {

@@ -971,7 +971,22 @@ extern "C" int64_t tmi_attn_workspace_bytes(int64_t B, int64_t H, int64_t Tq) {
   return Tq <= 128 ? B * H * 8 * Tq * (HD + 2) * 4 : 0;
 }
 
+static int tmi_attn_fwd_impl(const tmi_attn_desc* dp, void* stream);
 extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
+  if (tmi_plan_recording() && dp) {
+    const tmi_attn_desc c_ = *dp;
+    tmi_plan_push([c_, stream]() -> int {
+      tmi_attn_desc e_ = c_;
+      if (e_.dropout_p > 0.f) e_.dropout_seed += tmi_plan_seed_delta();
+      return tmi_attn_fwd(&e_, stream);
+    });
+  }
+  tmi_plan_enter();
+  const int rc_ = tmi_attn_fwd_impl(dp, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_attn_fwd_impl(const tmi_attn_desc* dp, void* stream) {
   if (!dp || !check_common(*dp)) {
     tmi_set_error("tmi_attn_fwd: bad argument (16-byte aligned bf16 operands, strides multiple of 8; dropout_p > 0 needs drop_mask of tmi_attn_dropmask_bytes)");
     return TMI_ERR_INVALID;
@@ -1015,7 +1030,22 @@ extern "C" int tmi_attn_fwd(const tmi_attn_desc* dp, void* stream) {
   return tmi_check_launch("tmi_attn_fwd");
 }
 
+static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream);
 extern "C" int tmi_attn_bwd(const tmi_attn_desc* dp, void* stream) {
+  if (tmi_plan_recording() && dp) {
+    const tmi_attn_desc c_ = *dp;
+    tmi_plan_push([c_, stream]() -> int {
+      tmi_attn_desc e_ = c_;
+      if (e_.dropout_p > 0.f) e_.dropout_seed += tmi_plan_seed_delta();
+      return tmi_attn_bwd(&e_, stream);
+    });
+  }
+  tmi_plan_enter();
+  const int rc_ = tmi_attn_bwd_impl(dp, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream) {
   if (!dp || !check_common(*dp) || !ok_mat(dp->d_o, dp->do_sb, dp->do_st) || !ok_mat(dp->dq, dp->dq_sb, dp->dq_st) ||
       !ok_mat(dp->dk, dp->dk_sb, dp->dk_st) || !ok_mat(dp->dv, dp->dv_sb, dp->dv_st) || !dp->delta) {
     tmi_set_error("tmi_attn_bwd: bad argument");

@@ -263,7 +263,22 @@ static bool fast_disabled() {
   return off;
 }
 
+static int tmi_gemm_impl(const tmi_gemm_desc* dp, void* stream);
 extern "C" int tmi_gemm(const tmi_gemm_desc* dp, void* stream) {
+  if (tmi_plan_recording() && dp) {
+    const tmi_gemm_desc c_ = *dp;
+    tmi_plan_push([c_, stream]() -> int {
+      tmi_gemm_desc e_ = c_;
+      if (e_.dropout_p > 0.f) e_.dropout_seed += tmi_plan_seed_delta();
+      return tmi_gemm(&e_, stream);
+    });
+  }
+  tmi_plan_enter();
+  const int rc_ = tmi_gemm_impl(dp, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_gemm_impl(const tmi_gemm_desc* dp, void* stream) {
   if (!dp) return TMI_ERR_INVALID;
   tmi_gemm_desc d = *dp;
   if (!d.A || !d.B || !d.C || d.M <= 0 || d.N <= 0 || d.K <= 0) {

@@ -380,7 +380,17 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+static int tmi_layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream);
 extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                                  float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || C > LN_MAX_C || C % vec ||
@@ -482,14 +492,42 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   return tmi_check_launch(what);
 }
 
+static int tmi_layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                 int32_t accumulate_dx, float* workspace, int64_t workspace_bytes, int32_t dtype, void* stream);
 extern "C" int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                                 const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                 int32_t accumulate_dx, float* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, workspace, workspace_bytes, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_layernorm_bwd_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, workspace, workspace_bytes, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_layernorm_bwd_impl(const void* dy, const void* x, const float* gamma, const float* mean,
                                  const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                                  int32_t accumulate_dx, float* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, nullptr, nullptr, 0.f, 0, dtype, stream,
                        "tmi_layernorm_bwd", workspace, workspace_bytes);
 }
 
+static int tmi_layernorm_bwd_emit_impl(const void* dy, const void* x, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                      int32_t accumulate_dx, float* colsum, void* masked, float dropout_p,
+                                      uint64_t dropout_seed, float* workspace, int64_t workspace_bytes, int32_t dtype,
+                                      void* stream);
 extern "C" int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float* gamma, const float* mean,
+                                      const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+                                      int32_t accumulate_dx, float* colsum, void* masked, float dropout_p,
+                                      uint64_t dropout_seed, float* workspace, int64_t workspace_bytes, int32_t dtype,
+                                      void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_layernorm_bwd_emit(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, colsum, masked, dropout_p, dropout_seed + tmi_plan_seed_delta(), workspace, workspace_bytes, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_layernorm_bwd_emit_impl(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, colsum, masked, dropout_p, dropout_seed, workspace, workspace_bytes, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_layernorm_bwd_emit_impl(const void* dy, const void* x, const float* gamma, const float* mean,
                                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                                       int32_t accumulate_dx, float* colsum, void* masked, float dropout_p,
                                       uint64_t dropout_seed, float* workspace, int64_t workspace_bytes, int32_t dtype,
@@ -502,7 +540,17 @@ extern "C" int tmi_layernorm_bwd_emit(const void* dy, const void* x, const float
                        dtype, stream, "tmi_layernorm_bwd_emit", workspace, workspace_bytes);
 }
 
+static int tmi_colsum_batched_impl(const void* dy, int64_t ld, int64_t dy_sb, float* out, int64_t out_sb, int64_t rows, int64_t N,
+                                  int64_t nbatch, int32_t dtype, void* stream);
 extern "C" int tmi_colsum_batched(const void* dy, int64_t ld, int64_t dy_sb, float* out, int64_t out_sb, int64_t rows, int64_t N,
+                                  int64_t nbatch, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_colsum_batched(dy, ld, dy_sb, out, out_sb, rows, N, nbatch, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_colsum_batched_impl(dy, ld, dy_sb, out, out_sb, rows, N, nbatch, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_colsum_batched_impl(const void* dy, int64_t ld, int64_t dy_sb, float* out, int64_t out_sb, int64_t rows, int64_t N,
                                   int64_t nbatch, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !out || rows <= 0 || N <= 0 || N % vec || ld % vec || !al16(dy) || nbatch <= 0 || nbatch > 65535 ||
@@ -527,12 +575,32 @@ extern "C" int tmi_colsum_batched(const void* dy, int64_t ld, int64_t dy_sb, flo
   return tmi_check_launch("tmi_colsum");
 }
 
+static int tmi_colsum_impl(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
+                          void* stream);
 extern "C" int tmi_colsum(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
+                          void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_colsum(dy, ld, out, rows, N, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_colsum_impl(dy, ld, out, rows, N, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_colsum_impl(const void* dy, int64_t ld, float* out, int64_t rows, int64_t N, int32_t dtype,
                           void* stream) {
   return tmi_colsum_batched(dy, ld, 0, out, 0, rows, N, 1, dtype, stream);
 }
 
+static int tmi_gelu_bwd_batched_impl(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
+                                    int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream);
 extern "C" int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
+                                    int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_gelu_bwd_batched(dy, u, dx, n, nbatch, dy_sb, u_sb, dx_sb, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_gelu_bwd_batched_impl(dy, u, dx, n, nbatch, dy_sb, u_sb, dx_sb, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_gelu_bwd_batched_impl(const void* dy, const void* u, void* dx, int64_t n, int64_t nbatch, int64_t dy_sb,
                                     int64_t u_sb, int64_t dx_sb, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !u || !dx || n <= 0 || nbatch <= 0 || nbatch > 65535 || n % vec || dy_sb % vec || u_sb % vec || dx_sb % vec ||
@@ -557,6 +625,14 @@ extern "C" int tmi_gelu_bwd_batched(const void* dy, const void* u, void* dx, int
   return tmi_check_launch("tmi_gelu_bwd");
 }
 
+static int tmi_gelu_bwd_impl(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream);
 extern "C" int tmi_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_gelu_bwd(dy, u, dx, n, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_gelu_bwd_impl(dy, u, dx, n, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_gelu_bwd_impl(const void* dy, const void* u, void* dx, int64_t n, int32_t dtype, void* stream) {
   return tmi_gelu_bwd_batched(dy, u, dx, n, 1, 0, 0, 0, dtype, stream);
 }

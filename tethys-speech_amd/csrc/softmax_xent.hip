@@ -356,7 +356,15 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+static int tmi_softmax_fwd_impl(float* s, int64_t rows, int64_t Tq, int64_t Tk, int32_t mask_mode, void* stream);
 extern "C" int tmi_softmax_fwd(float* s, int64_t rows, int64_t Tq, int64_t Tk, int32_t mask_mode, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_softmax_fwd(s, rows, Tq, Tk, mask_mode, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_softmax_fwd_impl(s, rows, Tq, Tk, mask_mode, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_softmax_fwd_impl(float* s, int64_t rows, int64_t Tq, int64_t Tk, int32_t mask_mode, void* stream) {
   if (!s || rows <= 0 || Tq <= 0 || Tk <= 0 || Tk > 64 * SM_E || (mask_mode != 0 && mask_mode != 1)) {
     tmi_set_error("tmi_softmax_fwd: bad argument (Tk <= 2048)");
     return TMI_ERR_INVALID;
@@ -366,7 +374,15 @@ extern "C" int tmi_softmax_fwd(float* s, int64_t rows, int64_t Tq, int64_t Tk, i
   return tmi_check_launch("tmi_softmax_fwd");
 }
 
+static int tmi_softmax_bwd_impl(const float* p, float* dp, int64_t rows, int64_t Tk, void* stream);
 extern "C" int tmi_softmax_bwd(const float* p, float* dp, int64_t rows, int64_t Tk, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_softmax_bwd(p, dp, rows, Tk, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_softmax_bwd_impl(p, dp, rows, Tk, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_softmax_bwd_impl(const float* p, float* dp, int64_t rows, int64_t Tk, void* stream) {
   if (!p || !dp || rows <= 0 || Tk <= 0 || Tk > 64 * SM_E) {
     tmi_set_error("tmi_softmax_bwd: bad argument");
     return TMI_ERR_INVALID;
@@ -399,12 +415,34 @@ static int xent_launch(void* logits, int64_t ld, const int32_t* labels, float* r
   return tmi_check_launch(what);
 }
 
+static int tmi_xent_fwd_bwd_impl(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
+                                int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream);
 extern "C" int tmi_xent_fwd_bwd(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
+                                int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_xent_fwd_bwd_impl(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_xent_fwd_bwd_impl(void* logits, int64_t ld, const int32_t* labels, float* row_loss, int64_t B,
                                 int64_t S, int64_t V, float grad_scale, int32_t dtype, void* stream) {
   return xent_launch(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, LmOperands{}, stream, "tmi_xent_fwd_bwd");
 }
 
+static int tmi_linear_xent_impl(const void* x, int64_t x_ld, const void* w, int64_t w_sk, int64_t w_sn, int64_t d, void* logits,
+                               int64_t ld, const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V,
+                               float grad_scale, int32_t dtype, void* stream);
 extern "C" int tmi_linear_xent(const void* x, int64_t x_ld, const void* w, int64_t w_sk, int64_t w_sn, int64_t d, void* logits,
+                               int64_t ld, const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V,
+                               float grad_scale, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_linear_xent(x, x_ld, w, w_sk, w_sn, d, logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_linear_xent_impl(x, x_ld, w, w_sk, w_sn, d, logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_linear_xent_impl(const void* x, int64_t x_ld, const void* w, int64_t w_sk, int64_t w_sn, int64_t d, void* logits,
                                int64_t ld, const int32_t* labels, float* row_loss, int64_t B, int64_t S, int64_t V,
                                float grad_scale, int32_t dtype, void* stream) {
   if (!x || !w || d <= 0 || d > (1 << 20) || x_ld < d || w_sk == 0 || w_sn == 0) {
@@ -416,7 +454,15 @@ extern "C" int tmi_linear_xent(const void* x, int64_t x_ld, const void* w, int64
   return xent_launch(logits, ld, labels, row_loss, B, S, V, grad_scale, dtype, lm, stream, "tmi_linear_xent");
 }
 
+static int tmi_sum_scale_impl(const float* x, float* out, int64_t n, float scale, void* stream);
 extern "C" int tmi_sum_scale(const float* x, float* out, int64_t n, float scale, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_sum_scale(x, out, n, scale, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_sum_scale_impl(x, out, n, scale, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_sum_scale_impl(const float* x, float* out, int64_t n, float scale, void* stream) {
   if (!x || !out || n <= 0) {
     tmi_set_error("tmi_sum_scale: bad argument");
     return TMI_ERR_INVALID;
@@ -426,7 +472,17 @@ extern "C" int tmi_sum_scale(const float* x, float* out, int64_t n, float scale,
   return tmi_check_launch("tmi_sum_scale");
 }
 
+static int tmi_embed_fwd_impl(const int32_t* labels, const float* table, const float* pe, void* out, int64_t B,
+                             int64_t S, int64_t D, int32_t start_id, int32_t dtype, void* stream);
 extern "C" int tmi_embed_fwd(const int32_t* labels, const float* table, const float* pe, void* out, int64_t B,
+                             int64_t S, int64_t D, int32_t start_id, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_embed_fwd(labels, table, pe, out, B, S, D, start_id, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_embed_fwd_impl(labels, table, pe, out, B, S, D, start_id, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_embed_fwd_impl(const int32_t* labels, const float* table, const float* pe, void* out, int64_t B,
                              int64_t S, int64_t D, int32_t start_id, int32_t dtype, void* stream) {
   if (!labels || !table || !pe || !out || B <= 0 || S <= 0 || D <= 0) {
     tmi_set_error("tmi_embed_fwd: bad argument");
@@ -445,7 +501,17 @@ extern "C" int tmi_embed_fwd(const int32_t* labels, const float* table, const fl
   return tmi_check_launch("tmi_embed_fwd");
 }
 
+static int tmi_embed_bwd_impl(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
+                             int64_t D, int32_t start_id, int32_t dtype, void* stream);
 extern "C" int tmi_embed_bwd(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
+                             int64_t D, int32_t start_id, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_embed_bwd(labels, dy, dtable, B, S, D, start_id, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_embed_bwd_impl(labels, dy, dtable, B, S, D, start_id, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_embed_bwd_impl(const int32_t* labels, const void* dy, float* dtable, int64_t B, int64_t S,
                              int64_t D, int32_t start_id, int32_t dtype, void* stream) {
   if (!labels || !dy || !dtable || B <= 0 || S <= 0 || D <= 0 || B * S > 16384) {
     tmi_set_error("tmi_embed_bwd: bad argument (B*S <= 16384)");

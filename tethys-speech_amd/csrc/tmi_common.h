@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include "../../include/tethys_mi.h"
 
 typedef __bf16 bf16_t;
@@ -18,6 +19,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 void tmi_set_error(const char* msg);
 int tmi_check_launch(const char* what);
 int tmi_deterministic();  // runtime.hip: tmi_set_deterministic
+
+// Launch plans (plan.hip).  Every launching entry point is a thin wrapper around its `_impl`: while this thread records a
+// plan (and is not already inside another entry point) the wrapper appends a closure that calls the entry point again
+// with the same arguments - copied by value, per-step ones (dropout seeds, the Adam step) offset by the replay's deltas.
+bool tmi_plan_recording();
+void tmi_plan_push(std::function<int()> fn);
+void tmi_plan_enter();
+void tmi_plan_leave();
+uint64_t tmi_plan_seed_delta();
+int64_t tmi_plan_step_delta();
 
 template <typename T> struct tmi_type;
 template <> struct tmi_type<float> { static constexpr int id = TMI_F32; };

@@ -806,7 +806,19 @@ static int gn_check(const void* x, int64_t B, int64_t T, int64_t C, int64_t G, i
   return 1;
 }
 
+static int tmi_groupnorm_gelu_fwd_impl(const void* x, int64_t x_sb, const float* gamma, const float* beta, void* y,
+                                      int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C,
+                                      int64_t G, float eps, int32_t dtype, void* stream);
 extern "C" int tmi_groupnorm_gelu_fwd(const void* x, int64_t x_sb, const float* gamma, const float* beta, void* y,
+                                      int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C,
+                                      int64_t G, float eps, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_groupnorm_gelu_fwd(x, x_sb, gamma, beta, y, y_sb, stats, part, B, T, C, G, eps, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_groupnorm_gelu_fwd_impl(x, x_sb, gamma, beta, y, y_sb, stats, part, B, T, C, G, eps, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_groupnorm_gelu_fwd_impl(const void* x, int64_t x_sb, const float* gamma, const float* beta, void* y,
                                       int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C,
                                       int64_t G, float eps, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
@@ -833,7 +845,21 @@ extern "C" int tmi_groupnorm_gelu_fwd(const void* x, int64_t x_sb, const float* 
   return tmi_check_launch("tmi_groupnorm_gelu_fwd");
 }
 
+static int tmi_groupnorm_gelu_bwd_impl(const void* x, int64_t x_sb, const void* dy, int64_t dy_sb, const float* gamma,
+                                      const float* beta, const float* stats, void* dx, int64_t dx_sb, float* dgamma,
+                                      float* dbeta, float* part, float* sums, int64_t B, int64_t T, int64_t C, int64_t G,
+                                      int32_t dtype, void* stream);
 extern "C" int tmi_groupnorm_gelu_bwd(const void* x, int64_t x_sb, const void* dy, int64_t dy_sb, const float* gamma,
+                                      const float* beta, const float* stats, void* dx, int64_t dx_sb, float* dgamma,
+                                      float* dbeta, float* part, float* sums, int64_t B, int64_t T, int64_t C, int64_t G,
+                                      int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_groupnorm_gelu_bwd(x, x_sb, dy, dy_sb, gamma, beta, stats, dx, dx_sb, dgamma, dbeta, part, sums, B, T, C, G, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_groupnorm_gelu_bwd_impl(x, x_sb, dy, dy_sb, gamma, beta, stats, dx, dx_sb, dgamma, dbeta, part, sums, B, T, C, G, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_groupnorm_gelu_bwd_impl(const void* x, int64_t x_sb, const void* dy, int64_t dy_sb, const float* gamma,
                                       const float* beta, const float* stats, void* dx, int64_t dx_sb, float* dgamma,
                                       float* dbeta, float* part, float* sums, int64_t B, int64_t T, int64_t C, int64_t G,
                                       int32_t dtype, void* stream) {
@@ -882,7 +908,21 @@ extern "C" int64_t tmi_fir_gn_workspace_floats(int64_t B, int64_t T, int64_t C) 
   return B * (a > b ? a : b) * 12 * C;
 }
 
+static int tmi_fir_groupnorm_gelu_fwd_impl(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const float* gamma, const float* beta, void* y,
+                                          int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          float eps, int32_t dtype, void* stream);
 extern "C" int tmi_fir_groupnorm_gelu_fwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const float* gamma, const float* beta, void* y,
+                                          int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          float eps, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_fir_groupnorm_gelu_fwd(audio, a_sb, Tin, pad_left, w, k, stride, gamma, beta, y, y_sb, stats, part, B, T, C, G, eps, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_fir_groupnorm_gelu_fwd_impl(audio, a_sb, Tin, pad_left, w, k, stride, gamma, beta, y, y_sb, stats, part, B, T, C, G, eps, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_fir_groupnorm_gelu_fwd_impl(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
                                           int64_t k, int64_t stride, const float* gamma, const float* beta, void* y,
                                           int64_t y_sb, float* stats, float* part, int64_t B, int64_t T, int64_t C, int64_t G,
                                           float eps, int32_t dtype, void* stream) {
@@ -907,7 +947,23 @@ extern "C" int tmi_fir_groupnorm_gelu_fwd(const float* audio, int64_t a_sb, int6
   return tmi_check_launch("tmi_fir_groupnorm_gelu_fwd");
 }
 
+static int tmi_fir_groupnorm_gelu_bwd_impl(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const void* dy, int64_t dy_sb, const float* gamma,
+                                          const float* beta, const float* stats, float* dW, float* dgamma, float* dbeta,
+                                          float* part, float* sums, float* wpart, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          int32_t dtype, void* stream);
 extern "C" int tmi_fir_groupnorm_gelu_bwd(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
+                                          int64_t k, int64_t stride, const void* dy, int64_t dy_sb, const float* gamma,
+                                          const float* beta, const float* stats, float* dW, float* dgamma, float* dbeta,
+                                          float* part, float* sums, float* wpart, int64_t B, int64_t T, int64_t C, int64_t G,
+                                          int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_fir_groupnorm_gelu_bwd(audio, a_sb, Tin, pad_left, w, k, stride, dy, dy_sb, gamma, beta, stats, dW, dgamma, dbeta, part, sums, wpart, B, T, C, G, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_fir_groupnorm_gelu_bwd_impl(audio, a_sb, Tin, pad_left, w, k, stride, dy, dy_sb, gamma, beta, stats, dW, dgamma, dbeta, part, sums, wpart, B, T, C, G, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_fir_groupnorm_gelu_bwd_impl(const float* audio, int64_t a_sb, int64_t Tin, int64_t pad_left, const float* w,
                                           int64_t k, int64_t stride, const void* dy, int64_t dy_sb, const float* gamma,
                                           const float* beta, const float* stats, float* dW, float* dgamma, float* dbeta,
                                           float* part, float* sums, float* wpart, int64_t B, int64_t T, int64_t C, int64_t G,
@@ -945,7 +1001,17 @@ extern "C" int tmi_fir_groupnorm_gelu_bwd(const float* audio, int64_t a_sb, int6
   return tmi_check_launch("tmi_fir_groupnorm_gelu_bwd");
 }
 
+static int tmi_group_pack_impl(const void* x, void* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t Tp,
+                              int64_t pad_left, int32_t dtype, void* stream);
 extern "C" int tmi_group_pack(const void* x, void* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t Tp,
+                              int64_t pad_left, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_group_pack(x, xg, B, T, C, G, Tp, pad_left, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_group_pack_impl(x, xg, B, T, C, G, Tp, pad_left, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_group_pack_impl(const void* x, void* xg, int64_t B, int64_t T, int64_t C, int64_t G, int64_t Tp,
                               int64_t pad_left, int32_t dtype, void* stream) {
   if (!x || !xg || B <= 0 || T <= 0 || C <= 0 || G <= 0 || C % G || Tp < T + pad_left || pad_left < 0) {
     tmi_set_error("tmi_group_pack: bad argument");
@@ -961,7 +1027,17 @@ extern "C" int tmi_group_pack(const void* x, void* xg, int64_t B, int64_t T, int
   return tmi_check_launch("tmi_group_pack");
 }
 
+static int tmi_group_unpack_impl(const void* yg, const float* bias, const void* resid, void* out, int64_t B, int64_t T,
+                                int64_t C, int64_t G, int64_t Tp, int64_t row_off, int32_t dtype, void* stream);
 extern "C" int tmi_group_unpack(const void* yg, const float* bias, const void* resid, void* out, int64_t B, int64_t T,
+                                int64_t C, int64_t G, int64_t Tp, int64_t row_off, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_group_unpack(yg, bias, resid, out, B, T, C, G, Tp, row_off, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_group_unpack_impl(yg, bias, resid, out, B, T, C, G, Tp, row_off, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_group_unpack_impl(const void* yg, const float* bias, const void* resid, void* out, int64_t B, int64_t T,
                                 int64_t C, int64_t G, int64_t Tp, int64_t row_off, int32_t dtype, void* stream) {
   if (!yg || !out || B <= 0 || T <= 0 || C <= 0 || G <= 0 || C % G || row_off < 0 || Tp < T + row_off) {
     tmi_set_error("tmi_group_unpack: bad argument");
@@ -976,7 +1052,17 @@ extern "C" int tmi_group_unpack(const void* yg, const float* bias, const void* r
   return tmi_check_launch("tmi_group_unpack");
 }
 
+static int tmi_posconv_pack_weights_impl(const float* w, void* wf, void* wb, int64_t k, int64_t Cg, int64_t G,
+                                        int32_t dtype, void* stream);
 extern "C" int tmi_posconv_pack_weights(const float* w, void* wf, void* wb, int64_t k, int64_t Cg, int64_t G,
+                                        int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_posconv_pack_weights(w, wf, wb, k, Cg, G, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_posconv_pack_weights_impl(w, wf, wb, k, Cg, G, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_posconv_pack_weights_impl(const float* w, void* wf, void* wb, int64_t k, int64_t Cg, int64_t G,
                                         int32_t dtype, void* stream) {
   if (!w || !wf || !wb || k <= 0 || Cg <= 0 || G <= 0) {
     tmi_set_error("tmi_posconv_pack_weights: bad argument");
@@ -991,7 +1077,17 @@ extern "C" int tmi_posconv_pack_weights(const float* w, void* wf, void* wb, int6
   return tmi_check_launch("tmi_posconv_pack_weights");
 }
 
+static int tmi_vq_nearest_impl(const void* h, const float* codebook, int32_t* idx, void* q, float* perplexity,
+                              int64_t rows, int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 extern "C" int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx, void* q, float* perplexity,
+                              int64_t rows, int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_vq_nearest(h, codebook, idx, q, perplexity, rows, G, Nc, gd, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_vq_nearest_impl(h, codebook, idx, q, perplexity, rows, G, Nc, gd, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_vq_nearest_impl(const void* h, const float* codebook, int32_t* idx, void* q, float* perplexity,
                               int64_t rows, int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream) {
   if (!h || !codebook || !idx || !q || !perplexity || rows <= 0 || G <= 0 || Nc <= 0 || gd <= 0 || gd > 1024 ||
       G * Nc > 8192) {
@@ -1009,7 +1105,17 @@ extern "C" int tmi_vq_nearest(const void* h, const float* codebook, int32_t* idx
   return tmi_check_launch("tmi_vq_nearest");
 }
 
+static int tmi_vq_assign_impl(const float* codebook, const int32_t* idx, void* q, float* perplexity, int64_t rows,
+                             int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream);
 extern "C" int tmi_vq_assign(const float* codebook, const int32_t* idx, void* q, float* perplexity, int64_t rows,
+                             int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_vq_assign(codebook, idx, q, perplexity, rows, G, Nc, gd, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_vq_assign_impl(codebook, idx, q, perplexity, rows, G, Nc, gd, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_vq_assign_impl(const float* codebook, const int32_t* idx, void* q, float* perplexity, int64_t rows,
                              int64_t G, int64_t Nc, int64_t gd, int32_t dtype, void* stream) {
   if (!codebook || !idx || !q || !perplexity || rows <= 0 || G <= 0 || Nc <= 0 || gd <= 0 || G * Nc > 8192) {
     tmi_set_error("tmi_vq_assign: bad argument");
@@ -1025,7 +1131,17 @@ extern "C" int tmi_vq_assign(const float* codebook, const int32_t* idx, void* q,
   return tmi_check_launch("tmi_vq_assign");
 }
 
+static int tmi_vq_bwd_impl(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G, int64_t Nc,
+                          int64_t gd, int32_t dtype, void* stream);
 extern "C" int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G, int64_t Nc,
+                          int64_t gd, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_vq_bwd(idx, dq, dcodebook, rows, G, Nc, gd, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_vq_bwd_impl(idx, dq, dcodebook, rows, G, Nc, gd, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_vq_bwd_impl(const int32_t* idx, const void* dq, float* dcodebook, int64_t rows, int64_t G, int64_t Nc,
                           int64_t gd, int32_t dtype, void* stream) {
   if (!idx || !dq || !dcodebook || rows <= 0 || G <= 0 || Nc <= 0 || gd <= 0) {
     tmi_set_error("tmi_vq_bwd: bad argument");
@@ -1040,7 +1156,19 @@ extern "C" int tmi_vq_bwd(const int32_t* idx, const void* dq, float* dcodebook, 
   return tmi_check_launch("tmi_vq_bwd");
 }
 
+static int tmi_contrastive_fwd_bwd_impl(float* S, const int32_t* neg, int64_t neg_sb, int64_t neg_st, float* row_loss,
+                                       int64_t B, int64_t T, int64_t Nn, float temperature, float grad_scale,
+                                       void* stream);
 extern "C" int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, int64_t neg_sb, int64_t neg_st, float* row_loss,
+                                       int64_t B, int64_t T, int64_t Nn, float temperature, float grad_scale,
+                                       void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_contrastive_fwd_bwd(S, neg, neg_sb, neg_st, row_loss, B, T, Nn, temperature, grad_scale, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_contrastive_fwd_bwd_impl(S, neg, neg_sb, neg_st, row_loss, B, T, Nn, temperature, grad_scale, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_contrastive_fwd_bwd_impl(float* S, const int32_t* neg, int64_t neg_sb, int64_t neg_st, float* row_loss,
                                        int64_t B, int64_t T, int64_t Nn, float temperature, float grad_scale,
                                        void* stream) {
   if (!S || !neg || !row_loss || B <= 0 || T <= 0 || Nn < 0 || T > 8192 || Nn > 4096 || temperature <= 0.f ||
@@ -1054,7 +1182,15 @@ extern "C" int tmi_contrastive_fwd_bwd(float* S, const int32_t* neg, int64_t neg
   return tmi_check_launch("tmi_contrastive_fwd_bwd");
 }
 
+static int tmi_segment_sumsq_impl(const float* g, const int64_t* seg_off, float* out, int64_t nseg, void* stream);
 extern "C" int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* out, int64_t nseg, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_segment_sumsq(g, seg_off, out, nseg, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_segment_sumsq_impl(g, seg_off, out, nseg, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_segment_sumsq_impl(const float* g, const int64_t* seg_off, float* out, int64_t nseg, void* stream) {
   if (!g || !seg_off || !out || nseg <= 0 || nseg > 65535) {
     tmi_set_error("tmi_segment_sumsq: bad argument");
     return TMI_ERR_INVALID;
@@ -1066,7 +1202,17 @@ extern "C" int tmi_segment_sumsq(const float* g, const int64_t* seg_off, float* 
   return tmi_check_launch("tmi_segment_sumsq");
 }
 
+static int tmi_segment_sumsq_chunks_impl(const float* g, const int64_t* chunks, int64_t nchunks, float* out, int64_t nseg,
+                                        void* stream);
 extern "C" int tmi_segment_sumsq_chunks(const float* g, const int64_t* chunks, int64_t nchunks, float* out, int64_t nseg,
+                                        void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_segment_sumsq_chunks(g, chunks, nchunks, out, nseg, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_segment_sumsq_chunks_impl(g, chunks, nchunks, out, nseg, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_segment_sumsq_chunks_impl(const float* g, const int64_t* chunks, int64_t nchunks, float* out, int64_t nseg,
                                         void* stream) {
   if (!g || !chunks || !out || nchunks <= 0 || nseg <= 0) {
     tmi_set_error("tmi_segment_sumsq_chunks: bad argument");
@@ -1079,7 +1225,17 @@ extern "C" int tmi_segment_sumsq_chunks(const float* g, const int64_t* chunks, i
   return tmi_check_launch("tmi_segment_sumsq_chunks");
 }
 
+static int tmi_segment_clip_impl(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,
+                                void* stream);
 extern "C" int tmi_segment_clip(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,
+                                void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_segment_clip(g, seg_off, sumsq, nseg, clip, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_segment_clip_impl(g, seg_off, sumsq, nseg, clip, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_segment_clip_impl(float* g, const int64_t* seg_off, const float* sumsq, int64_t nseg, float clip,
                                 void* stream) {
   if (!g || !seg_off || !sumsq || nseg <= 0 || nseg > 65535 || clip <= 0.f) {
     tmi_set_error("tmi_segment_clip: bad argument");
@@ -1091,7 +1247,15 @@ extern "C" int tmi_segment_clip(float* g, const int64_t* seg_off, const float* s
   return tmi_check_launch("tmi_segment_clip");
 }
 
+static int tmi_loss_combine_impl(const float* a, const float* b, float w, float scale, float* out, void* stream);
 extern "C" int tmi_loss_combine(const float* a, const float* b, float w, float scale, float* out, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_loss_combine(a, b, w, scale, out, stream); });
+  tmi_plan_enter();
+  const int rc_ = tmi_loss_combine_impl(a, b, w, scale, out, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+static int tmi_loss_combine_impl(const float* a, const float* b, float w, float scale, float* out, void* stream) {
   if (!a || !b || !out) {
     tmi_set_error("tmi_loss_combine: bad argument");
     return TMI_ERR_INVALID;

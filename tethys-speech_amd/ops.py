@@ -373,6 +373,29 @@ def attn_bwd(q, k, v, o, stats, do, dq, dk, dv, delta, B, H, Tq, Tk, mask_mode=0
         check(lib().tmi_attn_bwd(C.byref(d), stream()), "tmi_attn_bwd")
 
 
+def fill_zero(t):
+    """t[...] = 0 on the launch stream through the library (tmi_memset_async / tmi_memset2d_async), so that the fill is part
+    of a recorded launch plan: a torch ``zero_()`` between two recorded launches would be missing from every replay.
+    Contiguous tensors, or views whose slices along dim 0 are contiguous (the pad rows of a [B, T, C] buffer)."""
+    es = t.element_size()
+    if t.is_contiguous():
+        check(lib().tmi_memset_async(t.data_ptr(), 0, t.numel() * es, stream()), "tmi_memset_async")
+        return
+    if t.dim() < 2 or not t[0].is_contiguous():
+        raise ValueError("fill_zero: contiguous tensor or a view with contiguous slices along dim 0")
+    if t.numel() == 0:
+        return
+    check(lib().tmi_memset2d_async(t.data_ptr(), t.stride(0) * es, 0, t[0].numel() * es, t.shape[0], stream()),
+          "tmi_memset2d_async")
+
+
+def copy(dst, src):
+    """dst[...] = src[...] (same dtype and element count, both contiguous) on the launch stream, through the library."""
+    if dst.dtype != src.dtype or dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous():
+        raise ValueError("copy: contiguous tensors of one dtype and size")
+    check(lib().tmi_memcpy_async(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), stream()), "tmi_memcpy_async")
+
+
 def dropout(x, out, rows, cols, p, seed, resid=None):
     """out = (resid or 0) + Dropout_p(x) over [rows, cols] (row strides from the tensors); the same call on the
     incoming gradient, with the same seed, is the backward.  See tmi_dropout in include/tethys_mi.h."""

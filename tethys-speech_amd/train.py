@@ -84,6 +84,41 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer, pipelined=Fa
     return strategy.reduce_sum(loss.clone())
 
 
+# Launch plans (plan.py): the step recorded once per batch shape and replayed from one C call.  On by default for a single
+# replica on a GPU (TMI_PLAN=0: every step issued from Python); with replicas the RCCL collectives are issued through
+# torch.distributed between the launches, which the plan does not record - those jobs stay eager.
+USE_PLAN = os.environ.get("TMI_PLAN", "1") != "0"
+
+
+def plan_ok(strategy, model):
+    return (USE_PLAN and strategy.world == 1 and not strategy.force_collectives and model.device.type == "cuda"
+            and not ADAM_UNDER_BACKWARD)
+
+
+def planned_step(strategy, model, optimizer, kind="whisper", pipelined=True):
+    """``step(*inputs) -> loss`` for the training loops and the bench: ``distributed_train_step`` (kind "whisper": inputs
+    features, labels), ``wav2vec2_train_step`` ("wav2vec2": audio, neg_indices) or ``single_train_step`` ("single":
+    audio, neg_indices_t), through a launch plan when ``plan_ok`` and eagerly otherwise.  ``step.planned`` is the
+    PlannedStep (or None)."""
+    if kind == "whisper":
+        eager = lambda f, l: distributed_train_step(strategy, model, (f, l), optimizer, pipelined=pipelined)
+    elif kind == "wav2vec2":
+        eager = lambda audio, negs: wav2vec2_train_step(strategy, model, audio, negs, optimizer, pipelined=pipelined)
+    elif kind == "single":
+        eager = lambda audio, negs: single_train_step(model, audio, negs, optimizer)
+    else:
+        raise ValueError(kind)
+    if not plan_ok(strategy, model):
+        eager.planned = None
+        return eager
+    from .plan import PlannedStep
+    ps = PlannedStep(eager, model, optimizer, loss_buffer=lambda: model.ws["loss"],
+                     finish=lambda t: strategy.reduce_sum(t.clone()))
+    step = lambda *inputs: ps(*inputs)
+    step.planned = ps
+    return step
+
+
 class GraphedTrainStep:
     """``distributed_train_step`` for ONE replica, captured once as a HIP graph and replayed.
 

@@ -363,7 +363,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         sscale = 1.0 / math.sqrt(hd)
         if not getattr(a, "g_clean", False):
             self._wait_late()  # (a pending late Adam slice reads the gradients this fill would overwrite)
-            a.g.zero_()
+            ops.fill_zero(a.g)
         a.g_clean = False
 
         # ---- feature encoder (V:283-288): conv -> GroupNorm -> GELU, 7 times
@@ -522,7 +522,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                     self._dropout(dres, dy, site)
                 else:
                     self._guard_write(dy)
-                    dy.copy_(dres)
+                    ops.copy(dy, dres)
             return dy
 
         # The batched weight gradients go to the second stream in CHUNKS of layers (TMI_WGRAD_CHUNKS, default 4): a chunk

@@ -420,7 +420,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         scal_e, scal_d = (d // He) ** -0.5, (d // Hd) ** -0.5
         if not getattr(a, "g_clean", False):
             self._wait_late()  # (a pending late Adam slice reads the gradients this fill would overwrite)
-            a.g.zero_()  # (an optimizer step with zero_grad leaves the arena clean: no fill pass)
+            ops.fill_zero(a.g)  # (an optimizer step with zero_grad leaves the arena clean: no fill pass)
         a.g_clean = False
         done = [a.numel]
         expected = iter(self.grad_ready_names())
@@ -488,7 +488,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ops.feat_to_channels_last(features, xp0, B, Cn, T_in, self.pl1, self.pr1 + (xp0.shape[1] - self.Tp0))
         w1pad = ws.get("w1pad")
         if w1pad is not None:
-            w1pad[:3 * Cn].copy_(self.W("encoder.conv1.kernel")[0])
+            ops.copy(w1pad[:3 * Cn], self.W("encoder.conv1.kernel")[0])
             ops.gemm(xp0, w1pad, h1pad, self.T1, d, self.K1p, Cn, 1, d, 1, ldc=d, nbatch=B,
                      a_sb=xp0.stride(0), c_sb=h1pad.stride(0), c_off=self.pl2 * d,
                      bias=a.param("encoder.conv1.bias"), act=1, aux_out=u1pad)
@@ -572,13 +572,13 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # (K = 51904 against only B*S x d outputs: in bf16 mode reduce it split-K into fp32 and round once)
         if self.precision == "bf16":
             acc = ws["lmh_dx32"]
-            acc.zero_()
+            ops.fill_zero(acc)
             ops.gemm(logits, wl, acc, B * S, d, Vp, Vp, 1, 1, ldw, d, splitk=0)
             ops.cast_bf16(acc, d, dtmp, d, B * S, d)
         else:
             # (fp32 mode: the same split of the 51904-deep reduction, straight into the fp32 result)
             self._guard_write(dtmp)
-            dtmp.zero_()
+            ops.fill_zero(dtmp)
             ops.gemm(logits, wl, dtmp, B * S, d, Vp, Vp, 1, 1, ldw, d, splitk=0)
         if early_update is not None:
             # lm_head: gradient final (weight gradient above, same stream), weights read for the last time by the dgrad just
@@ -614,7 +614,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
             """dres for a deferred reader: the LayerNorm backward wrote ``buf`` (``have``) or it is copied now."""
             if not have:
                 self._guard_write(buf)
-                buf.copy_(dres)
+                ops.copy(buf, dres)
             return buf
 
         self._ln_bwd(dtmp, ws["dec_x"], "decoder.layer_norm", dres, "dec_ln", False, emit=ffn_emit("dec", Ld - 1, B * S))
@@ -731,7 +731,7 @@ class WhisperForConditionalGeneration(KernelBlocks):
         # ---- encoder backward
         dres = ws["dres_enc"]
         if cfg.decoder_layers == 0:
-            d_enc.zero_()
+            ops.fill_zero(d_enc)
         R = B * T
         self._ln_bwd(d_enc, ws["enc_x"], "encoder.layer_norm", dres, "enc_ln", False,
                      emit=ffn_emit("enc", cfg.encoder_layers - 1, R))
@@ -789,8 +789,8 @@ class WhisperForConditionalGeneration(KernelBlocks):
         ops.gemm(du2pad, w2, dh1pad, T, d, d, d, 1, 1, ld2, 2 * d, nbatch=B, a_sb=sd, c_sb=dh1pad.stride(0),
                  a_off=d, b_off=d * ld2, c_off=d, aux_in=u1pad)
         if self.pl2:
-            dh1pad[:, :self.pl2].zero_()
-        dh1pad[:, self.pl2 + self.T1:].zero_()
+            ops.fill_zero(dh1pad[:, :self.pl2])
+        ops.fill_zero(dh1pad[:, self.pl2 + self.T1:])
         ops.bias_grad(dh1pad.view(-1, d), a.grad("encoder.conv1.bias"))  # (pad rows were just zeroed)
         gw1 = a.grad("encoder.conv1.kernel").view(3 * Cn, d)
         ops.gemm(xp0, dh1pad, gw1, 3 * Cn, d, self.T1, 1, Cn, d, 1, d, kbatch=B, a_skb=xp0.stride(0),

@@ -43,7 +43,7 @@ python3 bench.py --workload wav2vec2 > $O/bench_wav2vec2_n1.json 2> $O/bench_wav
 python3 bench.py --workload whisper_single --batch_size 4 --steps 100 > $O/bench_whisper_single_n1.json 2> $O/bench_whisper_single_n1.log || true
 echo "bench lines done"
 python3 tools/host_step_time.py > $O/host_step_time.txt 2>&1 || true
-python3 tools/host_step_time_w2v.py >> $O/host_step_time.txt 2>&1 || true
+python3 tools/host_step_time.py wav2vec2 >> $O/host_step_time.txt 2>&1 || true
 python3 tools/lib_gemm_probe.py > $O/lib_gemm_probe.txt 2>&1 || true
 python3 tools/gemm_epi_probe.py > $O/gemm_epi_probe.txt 2>&1 || true
 python3 tools/gemm_f32_probe.py > $O/gemm_f32_probe.txt 2>&1 || true
