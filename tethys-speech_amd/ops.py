@@ -421,7 +421,9 @@ def embed_bwd(labels, dy, dtable, B, S, D, start_id):
 def xent_fwd_bwd(logits, ld, labels, row_loss, B, S, V, grad_scale, lm=None):
     """``lm = (x, x_ld, w, w_sk, w_sn, d)``: the logits are the LM head's output x . w - tmi_linear_xent takes the target logit of
     the loss from those operands in fp32 instead of from the bf16-rounded logits."""
-    with _probe("xent", 3.0 * B * S * V * logits.element_size()):
+    # (the kernel holds a row on chip: ONE read and one write of the logits, csrc/softmax_xent.hip - not the three passes of an
+    # unfused softmax + loss + gradient)
+    with _probe("xent", 2.0 * B * S * V * logits.element_size()):
         if lm is None:
             check(lib().tmi_xent_fwd_bwd(logits.data_ptr(), ld, labels.data_ptr(), row_loss.data_ptr(), B, S, V,
                                          grad_scale, dt(logits), stream()), "tmi_xent_fwd_bwd")
@@ -470,9 +472,11 @@ def adam_step_segments(p, g, m, v, n, chunks, sumsq, nseg, clip_global, clip_eac
 
 def adam_step_rows(p, g, m, v, nrows, row_len, active, lr, beta1, beta2, eps, step, eps_mode=0, gscale=1.0, mirror=None,
                    zero_grad=False):
-    """Adam over an embedding table, idle rows skipped (tmi_adam_step_rows).  Algorithmic bytes as the dense kernel's
-    (the probe prices what a dense update would move)."""
-    with _probe("adam", (28.0 + (2.0 if mirror is not None else 0.0)) * nrows * row_len):
+    """Adam over an embedding table, idle rows skipped (tmi_adam_step_rows).  Its own probe class: the ALGORITHMIC bytes are the
+    dense kernel's (28 B/param whatever the kernel skips), but it moves only the rows with a gradient or a
+    live moment (known on the device, not here) - bench.py reports the "adam" class from the dense launches (bytes really
+    moved) and the algorithmic figure, rows included, beside it."""
+    with _probe("adam_rows", (28.0 + (2.0 if mirror is not None else 0.0)) * nrows * row_len):
         check(lib().tmi_adam_step_rows(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), nrows, row_len,
                                        active.data_ptr(), lr, beta1, beta2, eps, step, eps_mode, 0.0, gscale, ptr(mirror),
                                        1 if zero_grad else 0, stream()), "tmi_adam_step_rows")
