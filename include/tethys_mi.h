@@ -38,8 +38,11 @@ int tmi_abi_version(void);
 /* Last HIP error string seen by a launch in this thread (host pointer, static storage). */
 const char* tmi_last_error(void);
 /* Reproducible reductions, process-wide, read at launch time (returns the previous setting).  On: tmi_colsum runs one
- * workgroup per column group, so no result depends on the arrival order of fp32 atomics; callers pair it with the
- * workspace (fixed-order fold) form of tmi_layernorm_bwd.  With both, a Whisper step is bit-reproducible (the reference,
+ * workgroup per column group and every library-chosen split-K that has to fall back to fp32 atomics is capped at two
+ * contributions per element (a + b = b + a; splits through workspace slabs are ordered anyway), so no result of those
+ * kernels depends on arrival order; callers pair it with the workspace (fixed-order fold) form of tmi_layernorm_bwd.
+ * Scope: the kernels of the WHISPER step - the Wav2Vec2 kernels that sum with atomics (GroupNorm parameter and codebook
+ * gradients) are not covered.  With both, a Whisper step is bit-reproducible (the reference,
  * TensorFlow on GPU, is not run-to-run reproducible either: no file:line to cite - this is a property the parity tests
  * use, tests/test_whisper_step_gpu.py). */
 int tmi_set_deterministic(int on);

@@ -794,8 +794,12 @@ def test_linear_xent_takes_the_target_logit_from_the_operands(dev, R_S, d, V, ld
     z = stored.double()[:, :V].view(B, S, V)               # what the kernel sees
     z_exact = (x.double() @ w.double())[:, :V].view(B, S, V)
     tgt = lab[:, 1:].long()
-    lse = torch.logsumexp(z[:, :-1], dim=-1)
-    want = lse - z_exact[:, :-1].gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    # the log-sum-exp over the stored logits with the TARGET's term taken at the recomputed logit too (both terms
+    # of the loss see the same target logit, so its rounding cancels where the target dominates)
+    zt_exact = z_exact[:, :-1].gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    zmix = z[:, :-1].clone()
+    zmix.scatter_(-1, tgt.unsqueeze(-1), zt_exact.unsqueeze(-1))
+    want = torch.logsumexp(zmix, dim=-1) - zt_exact
     got = rl.view(B, S)
     assert float(got[:, -1].abs().max()) == 0.0
     assert float((got[:, :-1].double() - want).abs().max()) <= 5e-5
@@ -803,6 +807,44 @@ def test_linear_xent_takes_the_target_logit_from_the_operands(dev, R_S, d, V, ld
     err_new = float((got[:, :-1].double() - full).abs().mean())
     err_old = float((rl_plain.view(B, S)[:, :-1].double() - full).abs().mean())
     assert err_new < 0.5 * err_old, (err_new, err_old)
+
+
+@pytest.mark.parametrize("V,ld", [(1000, 1024), (60001, 60032)])  # the on-chip-row kernel / the generic one
+def test_linear_xent_with_a_dominant_target_logit(dev, V, ld):
+    """a confident model - target logit ~ 20, every other ~ 0 - is where lse(rounded logits) - z_target(fp32)
+    keeps the rounding error of the stored target logit (half a bf16 ulp: 0.06 at |z| in [16, 32)) and can go negative.
+    With the target's term of the log-sum-exp at the recomputed logit as well, every row loss is >= 0 and at least as
+    close to the fp64 loss of the unrounded logits as the plain entry's."""
+    ops = _ops()
+    B, S, d = 2, 9, 64
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    lab = torch.randint(3, V, (B, S), generator=g, dtype=torch.int32).to(dev)
+    # row r reads feature r only: logits[r, :] = 3 * w[r, :]; w[r, target_r] ~ 6.3 .. 7.0 puts the row's target logit at
+    # 18.9 .. 21.1 (mostly off the bf16 grid, ulp 0.125 there), every other logit of the row is ~ 0.03
+    x = torch.zeros((B * S, d), dtype=bf, device=dev)
+    x[torch.arange(B * S), torch.arange(B * S)] = 3.0
+    w = (torch.randn((d, ld), generator=g) * 0.01).to(bf).to(dev)
+    w[:, V:] = 0
+    tg = torch.cat([lab[:, 1:], lab[:, :1]], dim=1).reshape(-1).long()   # target of row (b, t) = labels[b, t + 1]
+    w[torch.arange(B * S), tg] = torch.linspace(6.31, 7.03, B * S).to(bf).to(dev)
+    logits = torch.empty((B * S, ld), dtype=bf, device=dev)
+    ops.gemm(x, w, logits, B * S, ld, d, d, 1, ld, 1, ld)
+    plain = logits.clone()
+    rl_plain = torch.empty(B * S, dtype=torch.float32, device=dev)
+    rl = torch.empty_like(rl_plain)
+    gs = 1.0 / (B * (S - 1))
+    ops.xent_fwd_bwd(plain, ld, lab, rl_plain, B, S, V, gs)
+    ops.xent_fwd_bwd(logits, ld, lab, rl, B, S, V, gs, lm=(x, d, w, ld, 1, d))
+    torch.cuda.synchronize()
+    assert torch.equal(logits, plain)
+    ze = (x.double() @ w.double())[:, :V].view(B, S, V)[:, :-1]
+    tgt = lab[:, 1:].long()
+    full = torch.logsumexp(ze, dim=-1) - ze.gather(-1, tgt.unsqueeze(-1)).squeeze(-1)
+    got = rl.view(B, S)[:, :-1].double()
+    old = rl_plain.view(B, S)[:, :-1].double()
+    assert float(got.min()) >= 0.0, float(got.min())
+    assert float((got - full).abs().max()) <= float((old - full).abs().max()) + 1e-6, ((got - full).abs().max(), (old - full).abs().max())
 
 
 @pytest.mark.parametrize("eps_mode", [0, 1])
@@ -845,3 +887,75 @@ def test_casts_and_feats(dev):
     o = torch.empty(1, dtype=torch.float32, device=dev)
     ops.sumsq(x, o, x.numel())
     assert abs(float(o) - float((x.double() ** 2).sum())) <= 1e-4 * float((x.double() ** 2).sum())
+
+
+# ----------------------------------------------------------------------------- kernel-level reproducibility
+def _busy(dev, stream, seconds_of_kernels=0.004):
+    """Co-running filler on a second stream: uneven load is what exposed the round-4 attention hazard (stale MFMA
+    accumulators were read on SOME waves of SOME launches, more of them the busier the CU)."""
+    a = torch.randn(2048, 2048, device=dev)
+    with torch.cuda.stream(stream):
+        for _ in range(12):
+            a = torch.tanh(a @ a * 1e-3)
+    return a
+
+
+def test_kernels_are_bit_reproducible_under_load(dev):
+    """every hand-scheduled kernel launched TWICE on the same inputs, with other work running beside
+    it on a second stream, must give the same bits - tmi_attn_fwd and both passes of tmi_attn_bwd (with and without
+    dropout: the stored mask too), the eight-phase bf16 GEMM (persistent walk and plain, split-K dealt over XCDs through
+    workspace slabs) and the fp32-MFMA GEMM.  A VALU read of an MFMA result inside its hazard window (the round-4
+    attention bug) shows up here as a handful of differing elements; tools/check_mfma_hazards.py is the static half."""
+    ops = _ops()
+    bf = torch.bfloat16
+    side = torch.cuda.Stream(device=dev)
+
+    def twice(fn, outs):
+        got = []
+        for _ in range(2):
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            keep = _busy(dev, side)
+            fn()
+            torch.cuda.synchronize()
+            got.append([o.clone() for o in outs])
+            del keep
+        return all(torch.equal(a.view(torch.uint8), b.view(torch.uint8)) for a, b in zip(got[0], got[1]))
+
+    # attention: the encoder shape cut to 2 x 12 x 1500 (every tile kind: full tiles, the ragged last key tile) and the
+    # cross-attention shape with its key split + combine
+    for (B, H, Tq, Tk) in ((2, 12, 1500, 1500), (8, 12, 100, 1500)):
+        D = H * 64
+        q, k, v, do = (rnd((B, T, D), bf, dev, 60 + i, 0.5) for i, T in enumerate((Tq, Tk, Tk, Tq)))
+        o = torch.empty((B, Tq, D), dtype=bf, device=dev)
+        stats = torch.empty((B, H, Tq, 2), dtype=torch.float32, device=dev)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty((B, H, Tq), dtype=torch.float32, device=dev)
+        Q, K, V, Om = (q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D)
+        for p in (0.0, 0.1):
+            dm = ops.attn_dropmask(dev, B, H, Tq, Tk) if p > 0 else None
+            outs = [o, stats] + ([dm] if dm is not None else [])
+            assert twice(lambda: ops.attn_fwd(Q, K, V, Om, stats, B, H, Tq, Tk, 0, dropout_p=p, dropout_seed=5, drop_mask=dm), outs), \
+                f"tmi_attn_fwd not reproducible (B {B} Tq {Tq} Tk {Tk} p {p})"
+            ops.attn_fwd(Q, K, V, Om, stats, B, H, Tq, Tk, 0, dropout_p=p, dropout_seed=5, drop_mask=dm)
+            assert twice(lambda: ops.attn_bwd(Q, K, V, Om, stats, (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D),
+                                              (dv, 0, Tk * D, D), delta, B, H, Tq, Tk, 0, dropout_p=p, dropout_seed=5, drop_mask=dm),
+                         [dq, dk, dv, delta]), f"tmi_attn_bwd not reproducible (B {B} Tq {Tq} Tk {Tk} p {p})"
+    # GEMMs: forward FFN shape (eight-phase, persistent walk: 12000 x 3072 x 768), its N = 768 sibling (189 tiles, no
+    # persistence), the weight gradient (k-strided operands, fp32 out, split-K through slabs dealt over XCDs) and an fp32 one
+    M, d_, ff = 12000, 768, 3072
+    x = rnd((M, d_), bf, dev, 70, 0.5)
+    w1 = rnd((d_, ff), bf, dev, 71, 0.05)
+    w2 = rnd((ff, d_), bf, dev, 72, 0.05)
+    h = torch.empty((M, ff), dtype=bf, device=dev)
+    y = torch.empty((M, d_), dtype=bf, device=dev)
+    assert twice(lambda: ops.gemm(x, w1, h, M, ff, d_, d_, 1, ff, 1, ff), [h]), "bf16 GEMM 12000x3072x768 not reproducible"
+    ops.gemm(x, w1, h, M, ff, d_, d_, 1, ff, 1, ff)
+    assert twice(lambda: ops.gemm(h, w2, y, M, d_, ff, ff, 1, d_, 1, d_), [y]), "bf16 GEMM 12000x768x3072 not reproducible"
+    gw = torch.empty((d_, ff), dtype=torch.float32, device=dev)
+    assert twice(lambda: ops.gemm(x, h, gw, d_, ff, M, 1, d_, ff, 1, ff, splitk=0), [gw]), "weight-gradient GEMM (slab split-K) not reproducible"
+    a32 = rnd((1500, 768), torch.float32, dev, 73, 0.5)
+    b32 = rnd((768, 2304), torch.float32, dev, 74, 0.05)
+    c32 = torch.empty((1500, 2304), dtype=torch.float32, device=dev)
+    assert twice(lambda: ops.gemm(a32, b32, c32, 1500, 2304, 768, 768, 1, 2304, 1, 2304), [c32]), "fp32-MFMA GEMM not reproducible"

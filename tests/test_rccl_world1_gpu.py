@@ -105,6 +105,32 @@ def _worker(port, q):
         strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=64 * 1024, force_collectives=True)
         strat.exchange_off = True
         out[("early_buckets_off", "fp32")] = run(strat, "fp32", pipelined=True, tag=("early_buckets_off", "fp32"))
+        # the mesh form's all-to-all must not stall the ISSUING THREAD.  Its ``w.wait()`` (dist.py) is a
+        # stream-order dependency under RCCL (the exchange stream waits for the collective before the local fold; the host
+        # returns at once) - shown here by queueing ~50 ms of device work in front of the exchange: the issue path must be
+        # back long before that work, let alone the collective behind it, has finished.
+        import time
+        strat = D.DataParallelStrategy(0, 1, backend="nccl", exchange="mesh", grad_dtype="fp32", force_collectives=True)
+        g = torch.randn(1 << 20, device=dev)
+        g0 = g.clone()
+        strat._exchange(g, 0, g.numel())          # (staging buffers, exchange stream: first use)
+        torch.cuda.synchronize()
+        torch.cuda._sleep(100_000_000)            # ~50 ms on the compute stream; the exchange stream is ordered behind it
+        t0 = time.perf_counter()
+        strat.begin_gradients(g)
+        strat._exchange(g, 0, g.numel())
+        t_issue = time.perf_counter() - t0
+        done = torch.cuda.Event()
+        done.record(strat._xs)
+        still_running = not done.query()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        for w in strat._works:
+            w.wait()
+        for fn in strat._post:
+            fn()
+        torch.cuda.synchronize()
+        out["mesh_issue"] = (t_issue, t_all, still_running, bool(torch.equal(g, g0)))
         out["ran"] = ran
         torch.distributed.destroy_process_group()
         q.put(("ok", out))
@@ -136,6 +162,10 @@ def test_rccl_one_rank_exchange_is_the_identity(dev):
             (what, frac, float(dp.max()), float(dm.max()))
         return float(dp.max())
 
+    t_issue, t_all, still_running, same = out["mesh_issue"]
+    print(f"mesh exchange behind ~50 ms of queued work: issue path {t_issue * 1e3:.2f} ms, everything drained after {t_all * 1e3:.1f} ms")
+    assert still_running and t_issue < 0.25 * t_all, ("the mesh issue path waited for the device", t_issue, t_all, still_running)
+    assert same, "a one-rank mesh exchange must be the identity"
     for precision in ("fp32", "bf16"):
         plain = out[("plain", precision)]
         noise = close(out[("plain2", precision)], plain, ("plain twice", precision))

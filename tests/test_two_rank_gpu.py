@@ -336,3 +336,64 @@ def test_two_rank_whisper_step_matches_oracle(dev):
     ref, _ = TWH.O.train_steps(ocfg, params, feats, labels, 2, 4, lr=1e-3, n_replicas=2)
     assert max(abs(x - y) for x, y in zip(l0, ref)) <= 2e-4, (l0, ref)
 
+
+
+def _early_worker(rank, port, q, early, grad_dtype, exchange):
+    """ADVICE r4 (optim.py:126): the early Adam slices WITH replicas - the LM-head and embedding buckets updated on the
+    optimizer stream as soon as their own collective is done (optim.Adam.begin_early_buckets) - on two ranks with
+    DIFFERENT shards, against the same job with the early slices off (one update at the end of the step)."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import tethys_speech_amd  # noqa: F401
+        from tethys_speech_amd import dist as D, optim, train, whisper
+        torch.cuda.set_device(0)
+        dev = "cuda:0"
+        train.ADAM_EARLY = bool(early)
+        strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=64 * 1024, grad_dtype=grad_dtype, exchange=exchange)
+        model = whisper.create_whisper_model("small", device=dev, precision="bf16", seed=11, **KW)
+        strat.broadcast_parameters(model.arena.p)
+        model.refresh_shadows()
+        opt = optim.Adam(1e-3)
+        losses, ran = [], []
+        for f, l in _batches()[rank]:
+            out = train.distributed_train_step(strat, model, (torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)), opt,
+                                               pipelined=True)
+            losses.append(float(out.item()))
+            ran.append(int(getattr(opt, "early_buckets_ran", 0)))
+        model.finish_late()
+        torch.cuda.synchronize()
+        q.put((rank, "ok", model.arena.p.cpu().numpy(), losses, ran))
+        torch.distributed.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        q.put((rank, "error", f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None))
+
+
+@pytest.mark.parametrize("grad_dtype,exchange", [("fp32", "allreduce"), ("bf16", "mesh")])
+def test_two_rank_early_adam_buckets_leave_the_same_model(dev, grad_dtype, exchange):
+    ctx = mp.get_context("spawn")
+
+    def job(early):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_early_worker, args=(r, port, q, early, grad_dtype, exchange)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p_ in procs:
+            p_.join(60)
+        for r in res:
+            assert r[1] == "ok", r[2]
+        assert np.array_equal(res[0][2], res[1][2]), "replicas diverged"
+        return res[0]
+
+    _, _, p_on, l_on, ran_on = job(True)
+    _, _, p_off, l_off, ran_off = job(False)
+    assert all(n == 2 for n in ran_on), ("the early slices (LM head, embedding table) did not both run every step", ran_on)
+    assert all(n == 0 for n in ran_off), ran_off
+    # same per-parameter arithmetic either way (Adam is elementwise): equal up to the step's own fp32-atomic noise
+    assert np.allclose(l_on, l_off, rtol=1e-5, atol=1e-5), (l_on, l_off)
+    dp = np.abs(p_on - p_off)
+    assert float((dp > 1e-5).mean()) <= 2e-3 and float(np.median(dp)) <= 1e-7, (float(dp.max()), float((dp > 1e-5).mean()))

@@ -244,6 +244,7 @@ int launch(const tmi_gemm_desc& d, hipStream_t stream) {
     int64_t want = (512 + tiles - 1) / tiles;
     if (want > its / 4) want = its / 4;
     if (want > 64) want = 64;
+    if (tmi_deterministic() && want > 2) want = 2;  // (two atomic contributions per element commute; more do not)
     splitk = want < 1 ? 1 : (int)want;
   }
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splitk, (unsigned)(d.nbatch * (d.nbatch2 > 1 ? d.nbatch2 : 1)));

@@ -1510,6 +1510,9 @@ int launch_cfg(const tmi_gemm_desc& d, hipStream_t stream) {
       if (want > 5) want = 5;
       const int64_t budget = its * 160 * 1024 + 3 * 1048576;
       if (want > budget / out_bytes) want = budget / out_bytes;
+      // tmi_set_deterministic: at most TWO atomic contributions per element (a + b = b + a: the sum of two does not depend
+      // on the arrival order; three or more do - ADVICE r4)
+      if (tmi_deterministic() && want > 2) want = 2;
     }
     static const int force_split = [] { const char* e = getenv("TMI_GEMM_SPLIT"); return e ? atoi(e) : 0; }();
     if (force_split > 0) want = force_split < its ? force_split : its;
@@ -2057,6 +2060,7 @@ int launch_f32(const tmi_gemm_desc& d, hipStream_t stream) {
       if (want > d.workspace_bytes / slab_bytes) want = d.workspace_bytes / slab_bytes;
       ws_split = want > 1;
     } else if (want > 4) want = 4;
+    if (!use_ws && tmi_deterministic() && want > 2) want = 2;  // (two atomic contributions per element commute: launch_cfg)
     splitk = want < 1 ? 1 : (int)want;
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)(d.nbatch * (d.nbatch2 > 1 ? d.nbatch2 : 1)));

@@ -130,7 +130,21 @@ __global__ __launch_bounds__(256) void xent_kernel(T* __restrict__ logits, int64
   const float inv = 1.0f / gsum;
   float zt = 0.f;
   if (lm.x) zt = lm_target_logit(lm, row, target, red);  // (uniform over the block)
-  if (threadIdx.x == 0) row_loss[row] = lse - (lm.x ? zt : to_f32(lr[target]));
+  if (threadIdx.x == 0) {
+    // The loss's two terms must see the SAME target logit: with the fp32 recomputation z_t for the subtraction, the target's
+    // term of the log-sum-exp is swapped for exp(z_t) as well - otherwise a row whose target dominates (lse ~ rounded
+    // logit) keeps the rounding error of the stored logit, up to half a bf16 ulp, and can come out negative.
+    // The gradient is untouched (`inv` is the sum over the stored logits).
+    // Written as log1p(sum of the OTHER terms * exp(max - z_t)): non-negative by construction and free of the
+    // max + log(sum) - z_t cancellation (three numbers of size |z| for a result that may be 1e-6).
+    if (lm.x) {
+      const float rest = fmaxf(gsum - expf(to_f32(lr[target]) - gmx), 0.f);
+      const float dz = gmx - zt;
+      row_loss[row] = dz < 80.f ? log1pf(rest * expf(dz)) : dz + logf(rest);
+    } else {
+      row_loss[row] = lse - to_f32(lr[target]);
+    }
+  }
   __syncthreads();  // the target logit is read before anyone overwrites it
   for (int64_t ch = threadIdx.x; ch < nch; ch += 256) {
     const u32x4 raw = reinterpret_cast<const u32x4*>(lr)[ch];
@@ -248,7 +262,15 @@ __global__ __launch_bounds__(256, 4) void xent_rows_bf16_kernel(bf16_t* __restri
   const float inv = grad_scale / gsum;
   float zt = 0.f;
   if (lm.x) zt = lm_target_logit(lm, row, target, red);  // (uniform over the block)
-  if (threadIdx.x == 0) row_loss[row] = gmx + logf(gsum) - (lm.x ? zt : (float)lr[target]);
+  if (threadIdx.x == 0) {
+    if (lm.x) {  // (the log-sum-exp with the target's term at the recomputed logit too: see xent_kernel)
+      const float rest = fmaxf(gsum - __builtin_amdgcn_exp2f(fmaf((float)lr[target], L2E, nb)), 0.f);
+      const float dz = gmx - zt;
+      row_loss[row] = dz < 80.f ? log1pf(rest * expf(dz)) : dz + logf(rest);
+    } else {
+      row_loss[row] = gmx + logf(gsum) - (float)lr[target];
+    }
+  }
   __syncthreads();  // the target logit is read before anyone overwrites it
   const int tch = target >> 3, ti = target & 7;
   auto emit = [&](int ch, const u32x4& r) {

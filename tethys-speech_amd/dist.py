@@ -255,7 +255,12 @@ class DataParallelStrategy:
             else:  # mesh: piece j goes straight to rank j; fp32 sum of the N received pieces here
                 recv = self._buf((lo, hi, "recv"), padded, wire_dt, g)
                 w = dist.all_to_all_single(recv, wire, async_op=True)
-                w.wait()  # (orders the exchange stream after the all-to-all; the host does not block on RCCL)
+                # The local fold below reads ``recv``: the exchange stream has to be ordered after the all-to-all.  Under
+                # RCCL ``Work.wait()`` IS that stream-order dependency (hipStreamWaitEvent on the current stream - here the
+                # exchange stream - against the collective's own stream; the host returns at once:
+                # tests/test_rccl_world1_gpu.py times the issue path behind 50 ms of queued device work).  gloo has no
+                # streams: there it blocks, as every gloo collective of this class does (``_serial``).
+                w.wait()
                 red = self._buf((lo, hi, "red"), per, torch.float32, g)
                 self._unpack(recv, red, nparts=N, part_stride=per)
                 full = self._buf((lo, hi, "full"), padded, torch.float32, g)

@@ -478,6 +478,11 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # (K = Tp, not T: the pad columns of dS are zeros (tmi_cast_bf16 writes them), so the extra products vanish and the
         # launch takes the LDS-DMA kernels, whose k-contiguous operands come in whole 64-element K-tiles - with K = 99 it was
         # the step's only generic-kernel GEMM, 33 us for 40 MFLOP)
+        # NB: rows T .. Tp-1 of a sample's ``pq`` operand are the NEXT sample's first rows (or the buffer's zero
+        # tail) multiplied by exact zeros - a cross-sample read that is harmless only while ``pq`` is finite: an Inf / NaN in
+        # sample b + 1's pq would turn 0 * Inf into NaN in sample b's dph.  A step whose activations are not finite is lost
+        # either way (the loss is NaN), so the coupling costs nothing; it is stated here so that nobody relies on per-sample
+        # isolation of this product.
         ops.gemm(dS, ws["pq"], ws["dph"], T, pd, Tp, Tp, 1, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
         ops.gemm(dS, ws["ph"], ws["dpq"], T, pd, T, 1, Tp, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
         if drop:
