@@ -103,35 +103,55 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
   }
 }
 
-// fold chunk partials in double.  mode 0: -> (mean, rstd);  mode 1: -> (mean(dxhat), mean(dxhat*xhat))
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int BG,
-                                                         int G, int nchunks, double count, float eps, int mode) {
-  // one wave per (batch, group): lanes stride over the chunks, then a shuffle fold (fixed order)
-  const int i = blockIdx.x;
-  if (i >= BG) return;
-  const int b = i / G, g = i % G;
-  double a = 0.0, s = 0.0;
-  for (int c = threadIdx.x; c < nchunks; c += 64) {
-    const float* p = part + (((int64_t)b * nchunks + c) * G + g) * 2;
-    a += p[0];
-    s += p[1];
+// The fold of the chunk partials, done by the CONSUMER instead of a launch of its own (gn_finalize_kernel until round 4) (round 5: a 4.7 us kernel between two
+// others costs its duration plus a kernel boundary, 14 times per Wav2Vec2 step): every workgroup of an apply kernel folds
+// the chunk partials of ITS batch row - thread t takes group t % G and every (256 / G)-th chunk from t / G on, in double,
+// then the first G threads add the slices in slice order (a fixed association: the result is a function of the partials
+// alone) - and leaves (v0, v1) per group in `sh` ([2 * G] floats of LDS).  mode 0: (mean, rstd); mode 1: (mean(dxhat),
+// mean(dxhat * xhat)).  The workgroups with blockIdx.x == 0 also store the pairs to `out` (the backward reads the
+// statistics again).  `part` is L2-resident (written by the launch before) and 2 * nchunks * G floats per batch row.
+__device__ __forceinline__ void gn_fold_block(const float* __restrict__ part, int b, int G, int nchunks, double count, float eps,
+                                              int mode, float* __restrict__ sh, float* __restrict__ out) {
+  __shared__ double shd[512];
+  const int t = threadIdx.x;
+  const int nsub = G >= 256 ? 1 : 256 / G;
+  double a = 0.0, s_ = 0.0;
+  if (t < nsub * G) {
+    const int g = t % G, sub = t / G;
+    for (int c = sub; c < nchunks; c += nsub) {
+      const float* p = part + (((int64_t)b * nchunks + c) * G + g) * 2;
+      a += p[0];
+      s_ += p[1];
+    }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64);
-    s += __shfl_xor(s, o, 64);
+  shd[2 * t] = a;
+  shd[2 * t + 1] = s_;
+  __syncthreads();
+  if (t < G) {
+    double A = 0.0, S = 0.0;
+    for (int sub = 0; sub < nsub; ++sub) {
+      A += shd[2 * (sub * G + t)];
+      S += shd[2 * (sub * G + t) + 1];
+    }
+    float v0, v1;
+    if (mode == 0) {
+      const double mean = A / count;
+      double var = S / count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      v0 = (float)mean;
+      v1 = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      v0 = (float)(A / count);
+      v1 = (float)(S / count);
+    }
+    sh[2 * t] = v0;
+    sh[2 * t + 1] = v1;
+    if (out && blockIdx.x == 0) {
+      out[((int64_t)b * G + t) * 2] = v0;
+      out[((int64_t)b * G + t) * 2 + 1] = v1;
+    }
   }
-  if (threadIdx.x != 0) return;
-  if (mode == 0) {
-    const double mean = a / count;
-    double var = s / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    out[i * 2] = (float)mean;
-    out[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-  } else {
-    out[i * 2] = (float)(a / count);
-    out[i * 2 + 1] = (float)(s / count);
-  }
+  __syncthreads();
 }
 
 // forward apply: y = gelu(gamma * xhat + beta), written with its own batch stride (padded buffers)
@@ -139,17 +159,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const T* __restrict__ x, int64_t xsb,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
-                                                           const float* __restrict__ stats, T* __restrict__ y,
-                                                           int64_t ysb, int Tn, int C, int G) {
+                                                           float* __restrict__ stats, T* __restrict__ y,
+                                                           int64_t ysb, int Tn, int C, int G,
+                                                           const float* __restrict__ part, int nchunks, double count, float eps) {
   constexpr int VEC = 16 / sizeof(T);
   const int b = blockIdx.y;
   const int Cg = C / G;
+  __shared__ float shs[512];
+  gn_fold_block(part, b, G, nchunks, count, eps, 0, shs, stats);  // (mean, rstd) of this batch row's groups
   const int64_t nvec = (int64_t)Tn * C / VEC;
   // 256 * VEC is a multiple of C (gn_check), so a thread keeps its channels across the grid-stride loop:
   // gamma / beta / statistics are loaded once
   const int c0 = (int)(((int64_t)threadIdx.x * VEC) % C);
   const int g = c0 / Cg;
-  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float mean = shs[2 * g], rstd = shs[2 * g + 1];
   float gm[VEC], bt[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
@@ -180,14 +203,17 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ stats,
-                                                           const float* __restrict__ sums, T* __restrict__ dx,
+                                                           float* __restrict__ sums, T* __restrict__ dx,
                                                            int64_t dxsb, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int Tn, int C, int G,
-                                                           int rows_per_chunk) {
+                                                           int rows_per_chunk, const float* __restrict__ part, int nchunks,
+                                                           double count) {
   constexpr int VEC = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [rstep][2][C]
   const int b = blockIdx.y, chunk = blockIdx.x;
+  __shared__ float shs[512];
+  gn_fold_block(part, b, G, nchunks, count, 0.f, 1, shs, sums);  // (mean(dxhat), mean(dxhat * xhat)) of this batch row's groups
   const int Cg = C / G;
   const int cpr = C / VEC;
   const int c0 = (threadIdx.x % cpr) * VEC;
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const T* __restrict__
 #pragma unroll
   for (int i = 0; i < VEC; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; dg[i] = db[i] = 0.f; }
   const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-  const float m1 = sums[(b * G + g) * 2], m2 = sums[(b * G + g) * 2 + 1];
+  const float m1 = shs[2 * g], m2 = shs[2 * g + 1];
   if (threadIdx.x < cpr * rstep) {
     for (int r = r0 + rl; r < r1; r += rstep) {
       const int64_t off = (int64_t)r * C + c0;
@@ -364,12 +390,15 @@ __global__ __launch_bounds__(256) void fir_gn_partial_kernel(const float* __rest
 template <typename T, int KW, int S>
 __global__ __launch_bounds__(256) void fir_gn_apply_fwd_kernel(const float* __restrict__ audio, int64_t asb, int Tin, int pl,
                                                                const float* __restrict__ w, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, const float* __restrict__ stats,
+                                                               const float* __restrict__ beta, float* __restrict__ stats,
                                                                T* __restrict__ y, int64_t ysb, int Tn, int C, int G,
-                                                               int rows_per_chunk) {
+                                                               int rows_per_chunk, const float* __restrict__ part, int nchunks,
+                                                               double count, float eps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* win = reinterpret_cast<float*>(smem);
   const int b = blockIdx.y, chunk = blockIdx.x;
+  __shared__ float shs[512];
+  gn_fold_block(part, b, G, nchunks, count, eps, 0, shs, stats);
   const int Cg = C / G, cpr = C / 8;
   const int c0 = (threadIdx.x % cpr) * 8, g = c0 / Cg;
   const int rstep = 256 / cpr;
@@ -380,7 +409,7 @@ __global__ __launch_bounds__(256) void fir_gn_apply_fwd_kernel(const float* __re
   float gm[8], bt[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { gm[i] = gamma[c0 + i]; bt[i] = beta[c0 + i]; }
-  const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
+  const float mean = shs[2 * g], rstd = shs[2 * g + 1];
   __syncthreads();
   for (int r = r0 + threadIdx.x / cpr; r < r1; r += rstep) {
     float u[8];
@@ -398,12 +427,15 @@ __global__ __launch_bounds__(256) void fir_gn_apply_bwd_kernel(const float* __re
                                                                const float* __restrict__ w, const T* __restrict__ dy,
                                                                int64_t dysb, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* __restrict__ stats,
-                                                               const float* __restrict__ sums, float* __restrict__ wpart,
-                                                               int Tn, int C, int G, int rows_per_chunk, int nchunks) {
+                                                               float* __restrict__ sums, float* __restrict__ wpart,
+                                                               int Tn, int C, int G, int rows_per_chunk, int nchunks,
+                                                               const float* __restrict__ part, int npart, double count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* win = reinterpret_cast<float*>(smem);                       // [rows_per_chunk * S + KW]
   float* red = win + ((rows_per_chunk * S + KW + 3) & ~3);           // [rstep][C] fold buffer
   const int b = blockIdx.y, chunk = blockIdx.x;
+  __shared__ float shs[512];
+  gn_fold_block(part, b, G, npart, count, 0.f, 1, shs, sums);
   const int Cg = C / G, cpr = C / 8;
   const int c0 = (threadIdx.x % cpr) * 8, g = c0 / Cg;
   const int rstep = 256 / cpr, rl = threadIdx.x / cpr;
@@ -419,7 +451,7 @@ __global__ __launch_bounds__(256) void fir_gn_apply_bwd_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
   const float mean = stats[(b * G + g) * 2], rstd = stats[(b * G + g) * 2 + 1];
-  const float m1 = sums[(b * G + g) * 2], m2 = sums[(b * G + g) * 2 + 1];
+  const float m1 = shs[2 * g], m2 = shs[2 * g + 1];
   __syncthreads();
   for (int r = r0 + rl; r < r1; r += rstep) {
     const float* wr = win + (r - r0) * S;
@@ -834,14 +866,14 @@ static int tmi_groupnorm_gelu_fwd_impl(const void* x, int64_t x_sb, const float*
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 0>), gp, dim3(256), 0, s, (const bf16_t*)x, x_sb, (const bf16_t*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((gn_partial_kernel<float, 0>), gp, dim3(256), 0, s, (const float*)x, x_sb, (const float*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, stats, (int)(B * G),
-                     (int)G, nch, (double)T * (double)(C / G), eps, 0);
+  // (the fold of the chunk partials happens inside the apply kernel: gn_fold_block)
+  const double cnt = (double)T * (double)(C / G);
   int64_t blocks = (T * C / vec + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   dim3 ga((unsigned)blocks, (unsigned)B);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(gn_apply_fwd_kernel<bf16_t>, ga, dim3(256), 0, s, (const bf16_t*)x, x_sb, gamma, beta, stats, (bf16_t*)y, y_sb, (int)T, (int)C, (int)G),
-             hipLaunchKernelGGL(gn_apply_fwd_kernel<float>, ga, dim3(256), 0, s, (const float*)x, x_sb, gamma, beta, stats, (float*)y, y_sb, (int)T, (int)C, (int)G));
+             hipLaunchKernelGGL(gn_apply_fwd_kernel<bf16_t>, ga, dim3(256), 0, s, (const bf16_t*)x, x_sb, gamma, beta, stats, (bf16_t*)y, y_sb, (int)T, (int)C, (int)G, part, nch, cnt, eps),
+             hipLaunchKernelGGL(gn_apply_fwd_kernel<float>, ga, dim3(256), 0, s, (const float*)x, x_sb, gamma, beta, stats, (float*)y, y_sb, (int)T, (int)C, (int)G, part, nch, cnt, eps));
   return tmi_check_launch("tmi_groupnorm_gelu_fwd");
 }
 
@@ -876,14 +908,13 @@ static int tmi_groupnorm_gelu_bwd_impl(const void* x, int64_t x_sb, const void* 
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((gn_partial_kernel<bf16_t, 1>), gp, dim3(256), 0, s, (const bf16_t*)x, x_sb, (const bf16_t*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((gn_partial_kernel<float, 1>), gp, dim3(256), 0, s, (const float*)x, x_sb, (const float*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, sums, (int)(B * G),
-                     (int)G, nch, (double)T * (double)(C / G), 0.f, 1);
+  const double cnt = (double)T * (double)(C / G);
   const int cpr = (int)C / vec;
   const int rstep = 256 / cpr > 0 ? 256 / cpr : 1;
   const size_t lds = (size_t)rstep * 2 * C * sizeof(float);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(gn_apply_bwd_kernel<bf16_t>, gp, dim3(256), lds, s, (const bf16_t*)x, x_sb, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, (bf16_t*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc),
-             hipLaunchKernelGGL(gn_apply_bwd_kernel<float>, gp, dim3(256), lds, s, (const float*)x, x_sb, (const float*)dy, dy_sb, gamma, beta, stats, sums, (float*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc));
+             hipLaunchKernelGGL(gn_apply_bwd_kernel<bf16_t>, gp, dim3(256), lds, s, (const bf16_t*)x, x_sb, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, (bf16_t*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc, part, nch, cnt),
+             hipLaunchKernelGGL(gn_apply_bwd_kernel<float>, gp, dim3(256), lds, s, (const float*)x, x_sb, (const float*)dy, dy_sb, gamma, beta, stats, sums, (float*)dx, dx_sb, dgamma, dbeta, (int)T, (int)C, (int)G, rpc, part, nch, cnt));
   return tmi_check_launch("tmi_groupnorm_gelu_bwd");
 }
 
@@ -939,11 +970,10 @@ static int tmi_fir_groupnorm_gelu_fwd_impl(const float* audio, int64_t a_sb, int
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((fir_gn_partial_kernel<bf16_t, 10, 5, 0>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((fir_gn_partial_kernel<float, 10, 5, 0>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)nullptr, (int64_t)0, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, stats, (int)(B * G), (int)G, nch,
-                     (double)T * (double)(C / G), eps, 0);
+  const double cnt = (double)T * (double)(C / G);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<bf16_t, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (bf16_t*)y, y_sb, (int)T, (int)C, (int)G, rpc),
-             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<float, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (float*)y, y_sb, (int)T, (int)C, (int)G, rpc));
+             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<bf16_t, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (bf16_t*)y, y_sb, (int)T, (int)C, (int)G, rpc, part, nch, cnt, eps),
+             hipLaunchKernelGGL((fir_gn_apply_fwd_kernel<float, 10, 5>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, gamma, beta, stats, (float*)y, y_sb, (int)T, (int)C, (int)G, rpc, part, nch, cnt, eps));
   return tmi_check_launch("tmi_fir_groupnorm_gelu_fwd");
 }
 
@@ -982,8 +1012,7 @@ static int tmi_fir_groupnorm_gelu_bwd_impl(const float* audio, int64_t a_sb, int
   DISPATCH_T(dtype,
              hipLaunchKernelGGL((fir_gn_partial_kernel<bf16_t, 10, 5, 1>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch),
              hipLaunchKernelGGL((fir_gn_partial_kernel<float, 10, 5, 1>), gp, dim3(256), lds, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)dy, dy_sb, gamma, beta, stats, part, (int)T, (int)C, (int)G, rpc, nch));
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)(B * G)), dim3(64), 0, s, part, sums, (int)(B * G), (int)G, nch,
-                     (double)T * (double)(C / G), 0.f, 1);
+  const double cnt = (double)T * (double)(C / G);
   // the apply pass ends with a 12-quantity fold per workgroup and holds 256 registers: coarser chunks (one workgroup
   // per CU at base size) measured faster than the finer ones the other passes use (71 vs 84 us)
   const int nchA = (int)tmi_groupnorm_chunks(T);
@@ -993,8 +1022,8 @@ static int tmi_fir_groupnorm_gelu_bwd_impl(const float* audio, int64_t a_sb, int
   const int rstep = 256 / (int)(C / 8);
   const size_t lds2 = (size_t)(((nwinA + 3) & ~3) + rstep * C) * sizeof(float);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<bf16_t, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA),
-             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<float, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA));
+             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<bf16_t, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const bf16_t*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA, part, nch, cnt),
+             hipLaunchKernelGGL((fir_gn_apply_bwd_kernel<float, 10, 5>), gpA, dim3(256), lds2, s, audio, a_sb, (int)Tin, (int)pad_left, w, (const float*)dy, dy_sb, gamma, beta, stats, sums, wpart, (int)T, (int)C, (int)G, rpcA, nchA, part, nch, cnt));
   const int64_t rb = (12 * C + 255) / 256;
   const int64_t ry = B * nchA >= 64 ? 8 : 1;
   hipLaunchKernelGGL(fir_reduce_kernel, dim3((unsigned)rb, (unsigned)ry), dim3(256), 0, s, wpart, (int)(B * nchA), (int64_t)10 * C, C, dW, dgamma, dbeta);
