@@ -119,6 +119,16 @@ int tmi_gemm(const tmi_gemm_desc* d, void* stream);
 int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                       float* mean, float* rstd, int64_t rows, int64_t C, float eps,
                       int32_t dtype, void* stream);
+/* Dropout(LayerNorm(x)) in one pass and its gradient (V:296, V:560, V:779: `layer_norm` then `dropout`): the forward applies
+ * the flat dropout generator (tmi_dropout: stream 0, row, column of the [rows, C] output) to y on store; the backward
+ * applies the same mask to dy on load (the same seed), then runs tmi_layernorm_bwd.  dropout_p = 0: the plain entries. */
+int tmi_layernorm_dropout_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              int64_t rows, int64_t C, float eps, float dropout_p, uint64_t dropout_seed, int32_t dtype,
+                              void* stream);
+int tmi_layernorm_dropout_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                              void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int32_t accumulate_dx,
+                              float dropout_p, uint64_t dropout_seed, float* workspace, int64_t workspace_bytes,
+                              int32_t dtype, void* stream);
 int64_t tmi_layernorm_bwd_workspace_bytes(int64_t rows, int64_t C, int32_t emit);
 int tmi_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
                       const float* rstd, void* dx, float* dgamma, float* dbeta, int64_t rows,

@@ -889,6 +889,44 @@ def test_casts_and_feats(dev):
     assert abs(float(o) - float((x.double() ** 2).sum())) <= 1e-4 * float((x.double() ** 2).sum())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_dropout_fused_equals_layernorm_then_dropout(dev, dtype):
+    """tmi_layernorm_dropout_fwd / _bwd (V:296, V:560, V:779: LayerNorm then Dropout) against the two-launch form they
+    replace: the forward's output is tmi_dropout(tmi_layernorm_fwd(x)) (same generator, same counters), the backward
+    equals tmi_layernorm_bwd fed the tmi_dropout-masked dy - bit for bit in fp32 (dgamma / dbeta up to the order of their
+    atomics), to a rounding in bf16 (the fused passes round once where the two launches round twice) with the same zero
+    pattern - and the mask is the host generator's."""
+    from oracle import dropout as DO
+    ops = _ops()
+    rows, C, p, seed = 803, 768, 0.1, 0xABCDEF12345
+    x = rnd((rows, C), dtype, dev, 11, 1.3)
+    gamma = rnd((C,), torch.float32, dev, 12, 0.2) + 1.0
+    beta = rnd((C,), torch.float32, dev, 13, 0.2)
+    mean = torch.empty(rows, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    y_ref = torch.empty_like(x)
+    ops.layernorm_fwd(x, gamma, beta, y_ref, mean, rstd, 1e-5)
+    ln_only = y_ref.clone()
+    ops.dropout(y_ref, y_ref, rows, C, p, seed)
+    y = torch.empty_like(x)
+    ops.layernorm_dropout_fwd(x, gamma, beta, y, mean, rstd, 1e-5, p, seed)
+    exact = dtype == torch.float32  # (bf16: the two-launch form rounds LayerNorm's output, scales, and rounds again; the fused one rounds once)
+    assert torch.equal(y, y_ref) if exact else rel_err(y, y_ref) <= 1e-2
+    assert torch.equal(y != 0, y_ref != 0)
+    keep = torch.from_numpy(DO.keep_flat(seed, rows, C, p)).to(dev)
+    assert torch.equal(y != 0, keep & (ln_only != 0))
+    dy = rnd((rows, C), dtype, dev, 14)
+    dym = dy.clone()
+    ops.dropout(dym, dym, rows, C, p, seed)
+    dx_ref, dg_ref, db_ref = torch.empty_like(x), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.layernorm_bwd(dym, x, gamma, mean, rstd, dx_ref, dg_ref, db_ref)
+    dx, dg, db = torch.empty_like(x), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.layernorm_dropout_bwd(dy, x, gamma, mean, rstd, dx, dg, db, p, seed)
+    assert torch.equal(dx, dx_ref) if exact else rel_err(dx, dx_ref) <= 1.5e-2
+    tol_ = 1e-5 if exact else 1e-2
+    assert rel_err(dg, dg_ref) <= tol_ and rel_err(db, db_ref) <= tol_
+
+
 # ----------------------------------------------------------------------------- kernel-level reproducibility
 def _busy(dev, stream, seconds_of_kernels=0.004):
     """Co-running filler on a second stream: uneven load is what exposed the round-4 attention hazard (stale MFMA

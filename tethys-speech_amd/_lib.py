@@ -77,6 +77,8 @@ SIGNATURES = {
     "tmi_memcpy_async": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
     "tmi_gemm": (c_i32, [C.POINTER(GemmDesc), c_vp]),
     "tmi_layernorm_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_i32, c_vp]),
+    "tmi_layernorm_dropout_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_f32, C.c_uint64, c_i32, c_vp]),
+    "tmi_layernorm_dropout_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_f32, C.c_uint64, c_vp, c_i64, c_i32, c_vp]),
     "tmi_layernorm_bwd_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "tmi_layernorm_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp]),
     "tmi_colsum": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_vp]),
@@ -133,7 +135,7 @@ SIGNATURES = {
     "tmi_debug_gemm_stamps": (c_i32, [c_vp]),
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 _lib = None
 
 

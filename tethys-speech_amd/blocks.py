@@ -451,12 +451,17 @@ class KernelBlocks:
             self._guard_write(dx2d)
             dgrad()
 
-    def _ln_fwd(self, x2d, pname, y2d, stat):
+    def _ln_fwd(self, x2d, pname, y2d, stat, drop_site=None):
+        """``drop_site``: the LayerNorm is followed by Dropout (V:296, V:560, V:779): one pass writes Dropout(LayerNorm(x))."""
         a = self.arena
+        if drop_site is not None and self._drop_p > 0.0:
+            ops.layernorm_dropout_fwd(x2d, a.param(pname + ".gamma"), a.param(pname + ".beta"), y2d, self.ws[stat + ".mean"],
+                                      self.ws[stat + ".rstd"], self.layer_norm_eps, self._drop_p, self._site_seed(drop_site))
+            return
         ops.layernorm_fwd(x2d, a.param(pname + ".gamma"), a.param(pname + ".beta"), y2d,
                           self.ws[stat + ".mean"], self.ws[stat + ".rstd"], self.layer_norm_eps)
 
-    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate, emit=None):
+    def _ln_bwd(self, dy2d, x2d, pname, dx2d, stat, accumulate, emit=None, drop_site=None):
         """``emit`` = (bias gradient tensor, masked-copy buffer or None, dropout site or None): the Dense layer below this
         LayerNorm takes dx (or its Dropout-masked copy) as dy; its bias gradient and the masked copy come out of this
         kernel (tmi_layernorm_bwd_emit) instead of a dropout pass and a column-sum pass over dx.  A buffer without
@@ -464,9 +469,16 @@ class KernelBlocks:
         a = self.arena
         self._guard_write(dx2d)
         if emit is None:
+            if drop_site is not None and self._drop_p > 0.0:  # (the forward was _ln_fwd(..., drop_site): dy is masked on load)
+                ops.layernorm_dropout_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
+                                          dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), self._drop_p,
+                                          self._site_seed(drop_site), accumulate_dx=accumulate)
+                return
             ops.layernorm_bwd(dy2d, x2d, a.param(pname + ".gamma"), self.ws[stat + ".mean"], self.ws[stat + ".rstd"],
                               dx2d, a.grad(pname + ".gamma"), a.grad(pname + ".beta"), accumulate_dx=accumulate)
             return
+        if drop_site is not None:
+            raise ValueError("_ln_bwd: the emitting form has no mask on dy")
         colsum, masked, site = emit
         p = self._drop_p if (masked is not None and site is not None) else 0.0
         if masked is not None:

@@ -56,13 +56,31 @@ struct RowIO {
   }
 };
 
+// The flat dropout generator (tmi_keep: stream 0, row, column) applied to a lane's chunks of one row
+template <typename IO>
+__device__ __forceinline__ void drop_row(float (&v)[IO::E], uint32_t key, uint32_t row, int lane, uint32_t thr, float scale) {
+  const tmi_rowkey rk = tmi_row_key(key, row);
+#pragma unroll
+  for (int j = 0; j < IO::NCH; ++j) {
+    const uint32_t cp0 = (uint32_t)(((j * 64 + lane) * IO::VEC) >> 1);
+#pragma unroll
+    for (int i = 0; i < IO::VEC; i += 2) {
+      const uint32_t hh = tmi_pair_hash(rk, cp0 + (i >> 1));
+      const int e = j * IO::VEC + i;
+      v[e] = (hh & 0xffffu) >= thr ? v[e] * scale : 0.f;
+      v[e + 1] = (hh >> 16) >= thr ? v[e + 1] * scale : 0.f;
+    }
+  }
+}
+
 // Each wave walks rows blockIdx*4 + wave, + gridDim*4, ... with the next row's 16-byte loads
 // issued before the current row is reduced.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     int64_t rows, int C, float eps) {
+                                                     int64_t rows, int C, float eps, uint32_t drop_key, uint32_t drop_thr,
+                                                     float drop_scale) {
   using IO = RowIO<T, NCH>;
   constexpr int E = IO::E;
   const int lane = threadIdx.x & 63;
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const float rs = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int i = 0; i < E; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
+    if (drop_thr) drop_row<IO>(v, drop_key, (uint32_t)row, lane, drop_thr, drop_scale);  // Dropout(LayerNorm(x)) in one pass (V:296, V:560, V:779)
     IO::store(y + row * C, C, lane, v);
     if (lane == 0) {
       mean[row] = mu;
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
                                                      float* __restrict__ dbeta, int64_t rows, int C,
                                                      int accumulate_dx, float* __restrict__ colsum, T* __restrict__ masked,
                                                      uint32_t drop_key, uint32_t drop_thr, float drop_scale,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, uint32_t dy_key, uint32_t dy_thr, float dy_scale) {
   // EMIT: the residual-stream gradient this kernel writes (dx) is the dy of the Dense layer below it, whose bias
   // gradient is its column sum - and, where that layer's output went through Dropout (W:205, V:396, V:431), the dy is
   // the MASKED dx.  Both come out of this pass: colsum[c] += sum_rows (masked ? mask*dx : dx), masked[row][c] = mask*dx,
@@ -189,6 +208,8 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     IO::unpack(nx, xv);
     IO::unpack(ndy, dv);
     if (accumulate_dx) IO::unpack(nold, old);
+    // (the LayerNorm's output went through Dropout in the forward: its gradient is the masked, rescaled dy)
+    if (dy_thr) drop_row<IO>(dv, dy_key, (uint32_t)row, lane, dy_thr, dy_scale);
     const float mu = nmu, rs = nrs;
     const int64_t nr = row + step;
     if (nr < rows) {
@@ -380,22 +401,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
-static int tmi_layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream);
-extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
-  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream); });
-  tmi_plan_enter();
-  const int rc_ = tmi_layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream);
-  tmi_plan_leave();
-  return rc_;
-}
-static int tmi_layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
+static int ln_fwd_launch(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                         int64_t C, float eps, float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || C <= 0 || C > LN_MAX_C || C % vec ||
-      !al16(x) || !al16(y)) {
-    tmi_set_error("tmi_layernorm_fwd: bad argument (C must be a multiple of 16 bytes and <= 2048)");
+      !al16(x) || !al16(y) || !(dropout_p >= 0.f && tmi_drop_ok(dropout_p)) || (dropout_p > 0.f && (C & 1))) {
+    tmi_set_error("tmi_layernorm_fwd: bad argument (C must be a multiple of 16 bytes and <= 2048; 0 <= dropout_p < 1)");
     return TMI_ERR_INVALID;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -403,20 +414,43 @@ static int tmi_layernorm_fwd_impl(const void* x, const float* gamma, const float
   static const int64_t cap_f = [] { const char* e = getenv("TMI_LN_FWD_BLOCKS"); return e ? atoll(e) : 1024ll; }();
   const int64_t rpw = (rows + 4 * cap_f - 1) / (4 * cap_f);
   dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+  const uint32_t thr = tmi_drop_thr(dropout_p);
+  const uint32_t key = tmi_stream_key(dropout_seed, 0u);
+  const float scale = tmi_keep_scale(thr);
   if (dtype == TMI_BF16) {
     ln_dispatch<bf16_t>(C, [&](auto nch) {
       hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, decltype(nch)::value>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
-                         (bf16_t*)y, mean, rstd, rows, (int)C, eps);
+                         (bf16_t*)y, mean, rstd, rows, (int)C, eps, key, thr, scale);
     });
   } else if (dtype == TMI_F32) {
     ln_dispatch<float>(C, [&](auto nch) {
       hipLaunchKernelGGL((ln_fwd_kernel<float, decltype(nch)::value>), grid, dim3(256), 0, s, (const float*)x, gamma, beta,
-                         (float*)y, mean, rstd, rows, (int)C, eps);
+                         (float*)y, mean, rstd, rows, (int)C, eps, key, thr, scale);
     });
   } else {
     return TMI_ERR_UNSUPPORTED;
   }
   return tmi_check_launch("tmi_layernorm_fwd");
+}
+
+extern "C" int tmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int64_t rows, int64_t C, float eps, int32_t dtype, void* stream) {
+  if (tmi_plan_recording()) tmi_plan_push([=]() -> int { return tmi_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, C, eps, 0.f, 0, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
+}
+
+extern "C" int tmi_layernorm_dropout_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                         int64_t rows, int64_t C, float eps, float dropout_p, uint64_t dropout_seed, int32_t dtype,
+                                         void* stream) {
+  if (tmi_plan_recording())
+    tmi_plan_push([=]() -> int { return tmi_layernorm_dropout_fwd(x, gamma, beta, y, mean, rstd, rows, C, eps, dropout_p, dropout_seed + tmi_plan_seed_delta(), dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = ln_fwd_launch(x, gamma, beta, y, mean, rstd, rows, C, eps, dropout_p, dropout_seed, dtype, stream);
+  tmi_plan_leave();
+  return rc_;
 }
 
 static int64_t ln_bwd_blocks(int64_t rows) {
@@ -434,11 +468,12 @@ extern "C" int64_t tmi_layernorm_bwd_workspace_bytes(int64_t rows, int64_t C, in
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                          float* dgamma, float* dbeta, int64_t rows, int64_t C, int32_t accumulate_dx, float* colsum, void* masked,
                          float dropout_p, uint64_t dropout_seed, int32_t dtype, void* stream, const char* what,
-                         float* workspace, int64_t workspace_bytes) {
+                         float* workspace, int64_t workspace_bytes, float dy_dropout_p = 0.f, uint64_t dy_dropout_seed = 0) {
   const int vec = dtype == TMI_BF16 ? 8 : 4;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || C <= 0 || C > LN_MAX_C ||
       C % vec || !al16(x) || !al16(dy) || !al16(dx) || (masked && (!colsum || !al16(masked) || (C & 1))) ||
-      !(dropout_p >= 0.f && tmi_drop_ok(dropout_p))) {
+      !(dropout_p >= 0.f && tmi_drop_ok(dropout_p)) || !(dy_dropout_p >= 0.f && tmi_drop_ok(dy_dropout_p)) ||
+      (dy_dropout_p > 0.f && (C & 1))) {
     tmi_set_error("tmi_layernorm_bwd: bad argument");
     return TMI_ERR_INVALID;
   }
@@ -457,6 +492,8 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   const uint32_t thr = masked ? tmi_drop_thr(dropout_p) : 0u;
   const uint32_t key = tmi_stream_key(dropout_seed, 0u);
   const float scale = tmi_keep_scale(thr);
+  const uint32_t dy_thr = tmi_drop_thr(dy_dropout_p), dy_key = tmi_stream_key(dy_dropout_seed, 0u);
+  const float dy_scale = tmi_keep_scale(dy_thr);
   void* mk = masked;  // p == 0: the copy is dx itself (a snapshot for a deferred reader)
   auto go = [&](auto tag_t, auto nch, auto em) {
     using T = decltype(tag_t);
@@ -467,7 +504,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
     (void)attr;
     hipLaunchKernelGGL((ln_bwd_kernel<T, N, EM>), dim3((unsigned)blocks), dim3(64 * LNB_WAVES), lds, s, (const T*)dy, (const T*)x,
                        gamma, mean, rstd, (T*)dx, dgamma, dbeta, rows, (int)C, accumulate_dx, colsum, (T*)mk, key, thr, scale,
-                       workspace);
+                       workspace, dy_key, dy_thr, dy_scale);
   };
   if (dtype == TMI_BF16) {
     ln_dispatch<bf16_t>(C, [&](auto nch) {
@@ -509,6 +546,19 @@ static int tmi_layernorm_bwd_impl(const void* dy, const void* x, const float* ga
                                  int32_t accumulate_dx, float* workspace, int64_t workspace_bytes, int32_t dtype, void* stream) {
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, nullptr, nullptr, 0.f, 0, dtype, stream,
                        "tmi_layernorm_bwd", workspace, workspace_bytes);
+}
+
+extern "C" int tmi_layernorm_dropout_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                         void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t C, int32_t accumulate_dx,
+                                         float dropout_p, uint64_t dropout_seed, float* workspace, int64_t workspace_bytes,
+                                         int32_t dtype, void* stream) {
+  if (tmi_plan_recording())
+    tmi_plan_push([=]() -> int { return tmi_layernorm_dropout_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, dropout_p, dropout_seed + tmi_plan_seed_delta(), workspace, workspace_bytes, dtype, stream); });
+  tmi_plan_enter();
+  const int rc_ = ln_bwd_launch(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, accumulate_dx, nullptr, nullptr, 0.f, 0, dtype,
+                                stream, "tmi_layernorm_dropout_bwd", workspace, workspace_bytes, dropout_p, dropout_seed);
+  tmi_plan_leave();
+  return rc_;
 }
 
 static int tmi_layernorm_bwd_emit_impl(const void* dy, const void* x, const float* gamma, const float* mean,

@@ -29,5 +29,5 @@ extern "C" int tmi_set_deterministic(int on) {
   return was;
 }
 
-extern "C" int tmi_abi_version(void) { return 25; }
+extern "C" int tmi_abi_version(void) { return 26; }
 extern "C" const char* tmi_last_error(void) { return g_err; }

@@ -230,6 +230,26 @@ def ln_bwd_workspace(device, rows, C, emit):
     return ws
 
 
+def layernorm_dropout_fwd(x2d, gamma, beta, y2d, mean, rstd, eps, dropout_p, dropout_seed):
+    """y = Dropout_p(LayerNorm(x)) in one pass (tmi_layernorm_dropout_fwd): the mask of ``dropout`` over the [rows, C] output."""
+    with _probe("layernorm", 2.0 * x2d.numel() * x2d.element_size()):
+        rows, Cn = x2d.shape
+        check(lib().tmi_layernorm_dropout_fwd(x2d.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y2d.data_ptr(), mean.data_ptr(),
+                                              rstd.data_ptr(), rows, Cn, eps, dropout_p, dropout_seed, dt(x2d), stream()),
+              "tmi_layernorm_dropout_fwd")
+
+
+def layernorm_dropout_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, dropout_p, dropout_seed, accumulate_dx=False):
+    """layernorm_bwd of a LayerNorm whose output went through Dropout: the same mask (same seed) applied to dy on load."""
+    with _probe("layernorm", (4.0 if accumulate_dx else 3.0) * x2d.numel() * x2d.element_size()):
+        rows, Cn = x2d.shape
+        ws = ln_bwd_workspace(x2d.device, rows, Cn, False)
+        check(lib().tmi_layernorm_dropout_bwd(dy2d.data_ptr(), x2d.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              dx2d.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, Cn,
+                                              1 if accumulate_dx else 0, dropout_p, dropout_seed, ptr(ws),
+                                              0 if ws is None else ws.numel() * 4, dt(x2d), stream()), "tmi_layernorm_dropout_bwd")
+
+
 def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dx2d, dgamma, dbeta, accumulate_dx=False):
     """dgamma / dbeta are accumulated into: zero them first (the grad arena is)."""
     with _probe("layernorm", (4.0 if accumulate_dx else 3.0) * x2d.numel() * x2d.element_size()):

@@ -404,14 +404,10 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                          self.Tpp, 0)
         drop = self._drop_p > 0.0
         pa = self._drop_act_p
-        self._ln_fwd(ws["hp"], "feature_extractor.layer_norm", ws["feats"], "fe_ln")
-        if drop:
-            self._dropout(ws["feats"], ws["feats"], SITE_FE)  # V:296
+        self._ln_fwd(ws["hp"], "feature_extractor.layer_norm", ws["feats"], "fe_ln", drop_site=SITE_FE)  # V:296 (LayerNorm + Dropout, one pass)
         self._dense_fwd(ws["feats"], "feature_projection.kernel", ws["fp_pre"])
         hproj = ws["enc0.x_in"] if cfg.num_hidden_layers else ws["enc_x"]  # the encoder's input IS the projection
-        self._ln_fwd(ws["fp_pre"], "feature_projection_layer_norm", hproj, "fp_ln")
-        if drop:
-            self._dropout(hproj, hproj, SITE_FP)  # V:779 (the quantiser sees the dropped features too, V:784)
+        self._ln_fwd(ws["fp_pre"], "feature_projection_layer_norm", hproj, "fp_ln", drop_site=SITE_FP)  # V:779 (the quantiser sees the dropped features too, V:784)
 
         # ---- quantiser on the projected features (V:784): no gradient flows back through it
         Gq, Nc = cfg.num_codevector_groups, cfg.num_codevectors_per_group
@@ -424,9 +420,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
             ops.vq_nearest(ws["qin"], a.param("quantizer.codevectors"), ws["code_idx"], ws["quant"], ws["perplexity"], R,
                            Gq, Nc, gd)
         self._dense_fwd(ws["quant"], "project_q.dense.kernel", ws["pq_pre"])
-        self._ln_fwd(ws["pq_pre"], "project_q.layer_norm", ws["pq"], "pq_ln")
-        if drop:
-            self._dropout(ws["pq"], ws["pq"], SITE_PQ)  # V:560
+        self._ln_fwd(ws["pq_pre"], "project_q.layer_norm", ws["pq"], "pq_ln", drop_site=SITE_PQ)  # V:560
 
         # ---- encoder (V:419-439, stable layer norm)
         for i in range(cfg.num_hidden_layers):
@@ -454,9 +448,7 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # ---- projection head + contrastive loss (V:550-561, V:866-899)
         pd = cfg.proj_codevector_dim
         self._dense_fwd(ws["enc_x"], "project_hid.dense.kernel", ws["ph_pre"])
-        self._ln_fwd(ws["ph_pre"], "project_hid.layer_norm", ws["ph"], "ph_ln")
-        if drop:
-            self._dropout(ws["ph"], ws["ph"], SITE_PH)  # V:560
+        self._ln_fwd(ws["ph_pre"], "project_hid.layer_norm", ws["ph"], "ph_ln", drop_site=SITE_PH)  # V:560
         S = ws["S"]
         ops.gemm(ws["ph"], ws["pq"], S, T, T, pd, pd, 1, 1, pd, T, nbatch=B, a_sb=T * pd, b_sb=T * pd, c_sb=T * T)
         Nn = neg_indices.shape[1]
@@ -485,18 +477,16 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
         # isolation of this product.
         ops.gemm(dS, ws["pq"], ws["dph"], T, pd, Tp, Tp, 1, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
         ops.gemm(dS, ws["ph"], ws["dpq"], T, pd, T, 1, Tp, pd, 1, pd, nbatch=B, a_sb=T * Tp, b_sb=T * pd, c_sb=T * pd)
-        if drop:
-            self._dropout(ws["dpq"], ws["dpq"], SITE_PQ)
-            self._dropout(ws["dph"], ws["dph"], SITE_PH)
+        # (the Dropout behind each head's LayerNorm: its mask is applied to dpq / dph as the LayerNorm backward loads them)
         # project_q branch -> codebook
         # (the quantiser branch ends in the codebook: its dense backward and the codebook scatter feed nothing on the chain
         # and run on the second stream, from a buffer of their own - ws["dpd"] is reused by the other head at once)
-        self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd_q"], "pq_ln", False)
+        self._ln_bwd(ws["dpq"], ws["pq_pre"], "project_q.layer_norm", ws["dpd_q"], "pq_ln", False, drop_site=SITE_PQ)
         self._dense_bwd(ws["quant"], ws["dpd_q"], "project_q.dense.kernel", ws["dquant"], dgrad_on_side=True)
         gcode = a.grad("quantizer.codevectors")
         self._run_on_side(lambda: ops.vq_bwd(ws["code_idx"], ws["dquant"], gcode, R, Gq, Nc, gd), ws["dquant"])
         # project_hid branch -> encoder output
-        self._ln_bwd(ws["dph"], ws["ph_pre"], "project_hid.layer_norm", ws["dpd"], "ph_ln", False)
+        self._ln_bwd(ws["dph"], ws["ph_pre"], "project_hid.layer_norm", ws["dpd"], "ph_ln", False, drop_site=SITE_PH)
         dres = ws["dres"]
         self._dense_bwd(ws["enc_x"], ws["dpd"], "project_hid.dense.kernel", dres)
 
@@ -598,13 +588,9 @@ class Wav2Vec2ForPreTraining(KernelBlocks):
                 self._run_on_side(lambda lo=lo, hi=hi: encoder_weight_grads(lo, hi), ws[kk + "dqkv"])
 
         # hproj feeds the encoder only (the quantiser branch is non-differentiable)
-        if drop:
-            self._dropout(dres, dres, SITE_FP)
-        self._ln_bwd(dres, ws["fp_pre"], "feature_projection_layer_norm", ws["dtmp"], "fp_ln", False)
+        self._ln_bwd(dres, ws["fp_pre"], "feature_projection_layer_norm", ws["dtmp"], "fp_ln", False, drop_site=SITE_FP)
         self._dense_bwd(ws["feats"], ws["dtmp"], "feature_projection.kernel", ws["dfeats"])
-        if drop:
-            self._dropout(ws["dfeats"], ws["dfeats"], SITE_FE)
-        self._ln_bwd(ws["dfeats"], ws["hp"], "feature_extractor.layer_norm", ws["dhp"], "fe_ln", False)
+        self._ln_bwd(ws["dfeats"], ws["hp"], "feature_extractor.layer_norm", ws["dhp"], "fe_ln", False, drop_site=SITE_FE)
         dhp = ws["dhp"]
         # hp = h_last + posconv(h_last) + bias
         ops.bias_grad(dhp, a.grad("feature_extractor.pos_conv_embed.bias"))
