@@ -48,6 +48,8 @@ python3 tools/lib_gemm_probe.py > $O/lib_gemm_probe.txt 2>&1 || true
 python3 tools/gemm_epi_probe.py > $O/gemm_epi_probe.txt 2>&1 || true
 python3 tools/gemm_f32_probe.py > $O/gemm_f32_probe.txt 2>&1 || true
 python3 tools/attn_bench.py > $O/attn_bench.txt 2>&1 || true
+ATTN_DROPOUT=0.1 python3 tools/attn_bench.py >> $O/attn_bench.txt 2>&1 || true
+python3 tools/ln_bench.py > $O/ln_bench.txt 2>&1 || true
 TMI_GEMM_CFG=14 TMI_GEMM_P8_PERSIST=0 TMI_GEMM_DBG=16 python3 tools/p8_stamps.py > $O/p8_stamps.txt 2>&1 || true
 echo "all done"
 ls $O
