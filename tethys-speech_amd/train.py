@@ -238,12 +238,14 @@ def train_whisper(strategy, model_type="small", num_epochs=1, learning_rate=1e-4
             log(_step_line(i, lv, start_time, t0, time.time()))
             if report is not None:
                 report.log_step(i)
+    # (one replica on a GPU: the step is recorded once per batch shape and replayed from a launch plan, planned_step)
+    train_step = planned_step(strategy, model, optimizer, "whisper", pipelined=True)
     for epoch in range(num_epochs):
         log(f"Epoch {epoch + 1}/{num_epochs}")
         for _ in range(num_batches):
             inputs = next(it)
             step_start = time.time()
-            loss = distributed_train_step(strategy, model, inputs, optimizer, pipelined=True)
+            loss = train_step(*inputs)
             # the reference's loss.numpy() (W:951), fetched behind an event so the next step is enqueued meanwhile
             emit(fetch.push(loss, (step, step_start)))
             step += 1
@@ -460,6 +462,7 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
         for _ in range(step):  # the negative-index stream continues where the saved run stopped
             sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
     start_time = time.time()
+    train_step = planned_step(strategy, model, optimizer, "wav2vec2", pipelined=True)
     for epoch in range(num_epochs):
         log(f"{epoch_label} {epoch + 1}/{num_epochs}")
         for _ in range(num_batches):
@@ -469,7 +472,7 @@ def train_wav2vec2(strategy, model_type="pretraining", model_size="small", num_e
             neg_all = sample_negative_indices(rng, ds.global_batch, model.T, model.config.num_negatives)
             neg = torch.from_numpy(neg_all[strategy.rank * batch_size:(strategy.rank + 1) * batch_size]).to(device)
             step_start = time.time()
-            loss = wav2vec2_train_step(strategy, model, audio, neg, optimizer, pipelined=True)
+            loss = train_step(audio, neg)
             emit(fetch.push(loss, (step, step_start)))
             step += 1
             if checkpoint_dir and strategy.rank == 0 and step % 50 == 0:
