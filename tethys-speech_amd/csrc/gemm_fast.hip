@@ -45,6 +45,15 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
                : "memory");
 }
 
+// Diagnostic switches of the kernels below (in-kernel stamps, "skip the epilogue / the stores" ablations, TMI_GEMM_DBG): the
+// shipped library compiles them out - TMI_DBG(P) is the constant 0 and every `if (TMI_DBG(P) & ...)` folds away; a build with
+// make EXPERIMENTS=1 (-DTMI_GEMM_EXPERIMENTS) reads the field (tools/p8_stamps.py, tools/gemm_epi_probe.py need that build).
+#ifdef TMI_GEMM_EXPERIMENTS
+#define TMI_DBG(P) ((P).dbg)
+#else
+#define TMI_DBG(P) 0
+#endif
+
 struct FastParams {
   tmi_gemm_desc d;
   int tiles_m, tiles_n, ktiles;
@@ -54,7 +63,7 @@ struct FastParams {
   int wide;          // epilogue may use 16-byte accesses on C / aux / resid
   int64_t a_cols_rd; // KS operands: readable column count (multiple of 8)
   int64_t b_cols_rd;
-  int dbg;           // TMI_GEMM_DBG bit 1 (diagnostics only): skip the epilogue
+  int dbg;           // TMI_GEMM_DBG (diagnostics only; read through TMI_DBG: a constant 0 unless built with -DTMI_GEMM_EXPERIMENTS)
   uint32_t drop_thr, drop_key;  // epilogue dropout (desc.dropout_p): threshold (0 = off) and stream key
   float drop_scale;
   int64_t split_c_stride;  // != 0: split s stores (no atomics) to C + s * split_c_stride (workspace slabs)
@@ -380,7 +389,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
                                               int64_t mw, int64_t nw, int64_t bz, int lane, bool atomic) {
   asm volatile("" : "+v"(lane));  // (opaque: see lean_rows)
   const tmi_gemm_desc& d = P.d;
-  const bool st = (P.dbg & 32) && blockIdx.x == 8 && threadIdx.x < 64;
+  const bool st = (TMI_DBG(P) & 32) && blockIdx.x == 8 && threadIdx.x < 64;
   unsigned long long e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   if (st) e0 = stamp();
   {
@@ -393,7 +402,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
     }
   }
   if (st) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); e1 = stamp(); }
-  if (P.epi != EPI_GENERIC && !atomic && mw + 32 <= d.M && nw + 64 <= d.N && !(P.dbg & 8)) {  // (uniform over the wave)
+  if (P.epi != EPI_GENERIC && !atomic && mw + 32 <= d.M && nw + 64 <= d.N && !(TMI_DBG(P) & 8)) {  // (uniform over the wave)
     if (P.epi == EPI_SIMPLE) lean_rows<TC, EPI_SIMPLE, AHEAD>(P, E, mw, nw, bz, lane);
     else if (P.epi == EPI_AUXIN) lean_rows<TC, EPI_AUXIN, AHEAD>(P, E, mw, nw, bz, lane);
     else if (P.epi == EPI_RESID) lean_rows<TC, EPI_RESID, AHEAD>(P, E, mw, nw, bz, lane);
@@ -450,7 +459,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += t[i];
       }
-      if (aux_out && !(P.dbg & 8)) Vec8<TC>::store(aux_out + idx, v);
+      if (aux_out && !(TMI_DBG(P) & 8)) Vec8<TC>::store(aux_out + idx, v);
       if (d.act == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = gelu_fwd_t<TC>(v[i]);
@@ -466,7 +475,7 @@ __device__ __forceinline__ void wide_epilogue(const FastParams& P, const f32x16&
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += t[i];
       }
-      if (P.dbg & 8) { asm volatile("" ::"v"(v[0]), "v"(v[3]), "v"(v[7])); continue; }  // diagnostics: everything but the store
+      if (TMI_DBG(P) & 8) { asm volatile("" ::"v"(v[0]), "v"(v[3]), "v"(v[7])); continue; }  // diagnostics: everything but the store
       Vec8<TC>::store(C + idx, v);
     }
     if (st) {
@@ -917,7 +926,7 @@ void gemm_fast_kernel(const FastParams P) {
     }
   }
   if (!consumer) return;
-  if (P.dbg & 1) {
+  if (TMI_DBG(P) & 1) {
     if (acc[0][0][0] + acc[MI - 1][NI - 1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;  // keep acc live
     return;
   }
@@ -1284,7 +1293,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
         char* E = wave < 4 ? smem + last * P8_BUF + (1 + 2 * (wave >> 1)) * P8_HALF + (wave & 1) * 8192
                            : smem + 2 * P8_BUF + (wave - 4) * 8192;
         const int64_t mw0 = m0 + wr * WR, nw0 = n0 + wc * 64;
-        if (P.dbg & 1) {
+        if (TMI_DBG(P) & 1) {
           if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
         } else {
           // (written out: LLVM's pragma-unroll threshold declines four copies of the fp32 epilogue, and a rolled loop
@@ -1305,7 +1314,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (unread) stages
     return;
   } else {
-  const bool stamping = (P.dbg & 16) && blockIdx.x == 8 && blockIdx.y == 0 && wave == 0;  // diagnostics: where a tile's cycles go
+  const bool stamping = (TMI_DBG(P) & 16) && blockIdx.x == 8 && blockIdx.y == 0 && wave == 0;  // diagnostics: where a tile's cycles go
   unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
   if (stamping) ts[0] = stamp();
   if (nt > 0) {  // (uniform over the workgroup)
@@ -1336,7 +1345,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const FastParams P) {
     if (stamping) ts[3] = stamp();
   }
 
-  if (P.dbg & 1) {  // diagnostics: no epilogue (keep the accumulators live)
+  if (TMI_DBG(P) & 1) {  // diagnostics: no epilogue (keep the accumulators live)
     if (acc[0][0][0] + acc[NMI - 1][1][5] == 123.456f) reinterpret_cast<float*>(d.C)[0] = 0.f;
     return;
   }
@@ -1685,6 +1694,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
     });
   }
   dim3 grid((unsigned)(8 * P.ptm * P.ptn), (unsigned)splitk, (unsigned)d.nbatch);
+#ifdef TMI_GEMM_EXPERIMENTS
   if constexpr (sizeof(TC) == 2 && !A_KS && !B_KS && BM == 192) {  // diagnostics: TMI_GEMM_DBG & 6 = 2 no MFMA / reads, 4 no staging in the loop
     if ((dbg8 & 6) && splitk == 1) {
       auto kern = (dbg8 & 6) == 2 ? gemm_p8_kernel<TC, A_KS, B_KS, BM, false, 2> : gemm_p8_kernel<TC, A_KS, B_KS, BM, false, 4>;
@@ -1693,6 +1703,7 @@ int launch_p8(const tmi_gemm_desc& d, hipStream_t stream) {
       return tmi_check_launch("tmi_gemm(p8 ablation)");
     }
   }
+#endif
   if (splitk > 1) return launch_with_slabs(P, splitk, stream, [&](const FastParams& Q) {
     hipLaunchKernelGGL((gemm_p8_kernel<TC, A_KS, B_KS, BM>), grid, dim3(512), 2 * P8_BUF, stream, Q);
   });
