@@ -364,7 +364,7 @@ def timed_region(one_step, args, strategy, dev, world):
     return float(tmax.item()), float(loss.item()), t_host / args.steps * 1e3
 
 
-def exchange_diagnostics(one_step, args, strategy, dev, world, ms_with, host_ms):
+def exchange_diagnostics(without_exchange, args, strategy, dev, world, ms_with, host_ms):
     """What makes an N > 1 line diagnosable (every rank calls this; collectives inside):
       rccl_ranks            ranks that really took part: an all-reduce of ones over the job's backend
       exposed_exchange_ms   ms/step with the gradient exchange - ms/step of the SAME ranks with it left out
@@ -376,10 +376,10 @@ def exchange_diagnostics(one_step, args, strategy, dev, world, ms_with, host_ms)
     ones = torch.ones(1, dtype=torch.float32, device=dev)
     td.all_reduce(ones)
     k = max(5, min(args.steps, 30))
-    sub = argparse.Namespace(steps=k, warmup=2)
+    sub = argparse.Namespace(steps=k, warmup=3)   # (a fresh launch plan: two eager steps + the recorded one)
     strategy.exchange_off = True
     try:
-        dt_off, _, _ = timed_region(one_step, sub, strategy, dev, world)
+        dt_off, _, _ = without_exchange(lambda step: timed_region(step, sub, strategy, dev, world))
     finally:
         strategy.exchange_off = False
     hosts = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
@@ -521,13 +521,15 @@ def main():
             # timed region ends with a device-wide synchronize, which covers the last one
             return train.distributed_train_step(strategy, model, batch, opt, pipelined=True)
         # the same step through a launch plan (one replica: recorded once, then replayed from one C call; train.planned_step)
-        pstep = train.planned_step(strategy, model, opt, "whisper", pipelined=True)
+        plan_kind = "whisper"
+        pstep = train.planned_step(strategy, model, opt, plan_kind, pipelined=True)
+        cur = [pstep]
 
         def timed_step():
             batch = next(it)
             if batch[0].shape[0] != args.batch_size:
                 raise RuntimeError(f"rank {rank} drew {batch[0].shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
-            return pstep(*batch)
+            return cur[0](*batch)
         c = model.config
         metric = f"audio-seconds/sec/node (Whisper-{args.model_type}, 30 s clips)"
         workload = (f"whisper-{args.model_type}-ref (reference '{args.model_type}': {c.d_model}/{c.encoder_attention_heads}h/{c.d_ff}, "
@@ -561,14 +563,16 @@ def main():
                 raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
             # (pipelined: see the Whisper step above)
             return train.wav2vec2_train_step(strategy, model, audio, negs[ctr[0] % len(negs)], opt, pipelined=True)
-        pstep = train.planned_step(strategy, model, opt, "wav2vec2", pipelined=True)
+        plan_kind = "wav2vec2"
+        pstep = train.planned_step(strategy, model, opt, plan_kind, pipelined=True)
+        cur = [pstep]
 
         def timed_step():
             ctr[0] += 1
             audio = next(it)
             if audio.shape[0] != args.batch_size:
                 raise RuntimeError(f"rank {rank} drew {audio.shape[0]} clips instead of {args.batch_size}: not a weak-scaling step")
-            return pstep(audio, negs[ctr[0] % len(negs)])
+            return cur[0](audio, negs[ctr[0] % len(negs)])
         metric = f"audio-seconds/sec/node (Wav2Vec2-{size} pretrain step, 2 s clips)"
         workload = f"wav2vec2-{size} pre-training step (V:), per-GPU batch {args.batch_size}, 2 s clips [32000]"
         gf_sample = W2V_GF_PER_SAMPLE.get(size)
@@ -604,13 +608,25 @@ def main():
     plan_note = None
     if getattr(pstep, "planned", None) is not None:
         pl = [v["plan"] for v in pstep.planned._by_sig.values() if v.get("plan") is not None]
-        plan_note = {"replayed_steps": pstep.planned.replays, "launches": [p_.launches for p_ in pl], "nodes": [p_.nodes for p_ in pl]}
+        plan_note = {"replayed_steps": pstep.planned.replays, "launches": [p_.launches for p_ in pl], "nodes": [p_.nodes for p_ in pl],
+                     "host_callbacks": [p_.callbacks for p_ in pl]}
         log(f"launch plan: {plan_note}")
     log(f"timed {args.steps} steps: {dt / args.steps * 1e3:.2f} ms/step, loss {last_loss:.4f}")
 
     multi = None
     if world > 1:
-        multi = exchange_diagnostics(one_step, args, strategy, dev, world, dt / args.steps * 1e3, host_ms)
+        # the same ranks without the exchange, issued the same way as the timed steps: a launch plan of its own (the recorded
+        # launch sequence differs), or the eager step with --no-plan
+        def without_exchange(run):
+            if args.no_plan:
+                return run(one_step)
+            keep = cur[0]
+            cur[0] = train.planned_step(strategy, model, opt, plan_kind, pipelined=True)
+            try:
+                return run(timed_step)
+            finally:
+                cur[0] = keep
+        multi = exchange_diagnostics(without_exchange, args, strategy, dev, world, dt / args.steps * 1e3, host_ms)
 
     roof = classes = None
     if not args.no_roofline:

@@ -340,7 +340,7 @@ def _bench_worker(rank, world, port, q):
     dt, last, host_ms = bench.timed_region(one_step, args, strat, "cpu", world)
     nseen = len(seen)
     # the N > 1 diagnostics of the bench line (VERDICT r2 item 5 ii): every rank calls it, collectives inside
-    diag = bench.exchange_diagnostics(one_step, args, strat, "cpu", world, dt / args.steps * 1e3, host_ms)
+    diag = bench.exchange_diagnostics(lambda run: run(one_step), args, strat, "cpu", world, dt / args.steps * 1e3, host_ms)
     assert strat.exchange_off is False
     q.put((rank, dt, torch.stack(seen[:nseen]).numpy(), bench.throughput(30.0, 4, world, args.steps, dt), diag))
     dist.destroy_process_group()
@@ -484,3 +484,55 @@ def test_no_valu_read_inside_an_mfma_hazard_window():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_hazards.py"), lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 candidate hazard(s) in" in r.stdout and " 0 code object" not in r.stdout
+
+
+def test_launch_plan_callback_nodes_replay_in_order_and_raise():
+    """plan.host_call (the collectives of a job with replicas inside a recorded step): the function runs at once while the
+    plan records, every replay calls it again at its place of the sequence, a ``WorkSlot`` is refilled by each replay, and
+    an exception inside a callback comes out of ``replay`` (no GPU: the plan holds callback nodes only)."""
+    from tethys_speech_amd import plan as P
+    seen, slot = [], P.WorkSlot()
+
+    class Work:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def wait(self):
+            seen.append(("wait", self.tag))
+
+    issued = [0]
+
+    def issue():
+        issued[0] += 1
+        slot.work = Work(issued[0])
+        seen.append(("issue", issued[0]))
+
+    P.host_call(lambda: seen.append("outside"))   # no plan recording: just a call
+    pl = P.LaunchPlan()
+    with pl.recording():
+        P.host_call(issue)
+        slot.wait()
+    assert seen == ["outside", ("issue", 1), ("wait", 1)] and pl.callbacks == 2 and pl.nodes == 2 and pl.launches == 0
+    pl.replay()
+    pl.replay()
+    assert seen[3:] == [("issue", 2), ("wait", 2), ("issue", 3), ("wait", 3)]
+    P.host_call(lambda: seen.append("after"))     # the recording is over: not a node
+    assert pl.callbacks == 2
+
+    bad = P.LaunchPlan()
+    fail = [False]
+
+    def maybe():
+        if fail[0]:
+            raise RuntimeError("collective failed")
+    later = []
+    with bad.recording():
+        P.host_call(maybe)
+        P.host_call(lambda: later.append(1))
+    fail[0] = True
+    with pytest.raises(RuntimeError, match="collective failed"):
+        bad.replay()
+    assert later == [1], "nodes after a failed callback must not issue anything"
+    fail[0] = False
+    bad.replay()
+    assert later == [1, 1]

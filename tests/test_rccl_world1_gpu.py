@@ -26,10 +26,10 @@ STEPS = 3
 FORMS = [(ex, dt) for ex in ("allreduce", "rs_ag", "mesh") for dt in ("fp32", "bf16")]
 
 
-def _batches():
+def _batches(steps=STEPS):
     rng = np.random.default_rng(21)
     return [(rng.standard_normal((2, 16, 48)).astype(np.float32), rng.integers(0, 150, (2, 12)).astype(np.int32))
-            for _ in range(STEPS)]
+            for _ in range(steps)]
 
 
 def _free_port():
@@ -105,6 +105,36 @@ def _worker(port, q):
         strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=64 * 1024, force_collectives=True)
         strat.exchange_off = True
         out[("early_buckets_off", "fp32")] = run(strat, "fp32", pipelined=True, tag=("early_buckets_off", "fp32"))
+        # Launch plans with replicas (plan.host_call): the collectives and their Work.wait()s are callback nodes of the
+        # recorded step.  Six pipelined steps - two eager, one recorded, three replayed - against the same six issued
+        # from Python, per exchange form (RCCL Work objects refilled by every replay, waits on the exchange and optimizer
+        # streams, the early-bucket Adam slices, the staging fills / copies of rs_ag and mesh as library launches).
+        def run6(strat, precision, planned):
+            model = whisper.create_whisper_model("small", device=dev, precision=precision, seed=11, **KW)
+            strat.broadcast_parameters(model.arena.p)
+            model.refresh_shadows()
+            opt = optim.Adam(1e-3)
+            if planned:
+                step = train.planned_step(strat, model, opt, "whisper", pipelined=True)
+                assert step.planned is not None, "train.plan_ok refused a job with replicas"
+            else:
+                step = lambda f, l: train.distributed_train_step(strat, model, (f, l), opt, pipelined=True)
+            losses = [step(torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)) for f, l in _batches(6)]
+            losses = [float(x.item()) for x in losses]
+            model.finish_late()
+            torch.cuda.synchronize()
+            info = None
+            if planned:
+                pl = [v["plan"] for v in step.planned._by_sig.values() if v.get("plan") is not None]
+                info = (step.planned.replays, [p_.callbacks for p_ in pl], [p_.launches for p_ in pl])
+            return (losses, model.arena.p.cpu().numpy(), model.arena.m.cpu().numpy()), info
+
+        for ex, dt, precision in (("allreduce", "fp32", "fp32"), ("allreduce", "fp32", "bf16"), ("rs_ag", "fp32", "fp32"),
+                                  ("mesh", "bf16", "fp32")):
+            for planned in (False, True):
+                strat = D.DataParallelStrategy(0, 1, backend="nccl", bucket_bytes=64 * 1024, exchange=ex, grad_dtype=dt,
+                                               force_collectives=True)
+                out[("six", ex, dt, precision, planned)] = run6(strat, precision, planned)
         # the mesh form's all-to-all must not stall the ISSUING THREAD.  Its ``w.wait()`` (dist.py) is a
         # stream-order dependency under RCCL (the exchange stream waits for the collective before the local fold; the host
         # returns at once) - shown here by queueing ~50 ms of device work in front of the exchange: the issue path must be
@@ -183,6 +213,13 @@ def test_rccl_one_rank_exchange_is_the_identity(dev):
                 assert np.allclose(l1, l0, rtol=2e-3, atol=2e-3), (ex, dt, precision, l1, l0)
                 den = np.abs(m0).max()
                 assert np.abs(m1 - m0).max() <= 1e-2 * den, (ex, dt, precision, np.abs(m1 - m0).max(), den)
+    for ex, dt, precision in (("allreduce", "fp32", "fp32"), ("allreduce", "fp32", "bf16"), ("rs_ag", "fp32", "fp32"),
+                              ("mesh", "bf16", "fp32")):
+        eager, _ = out[("six", ex, dt, precision, False)]
+        planned, (replays, callbacks, launches) = out[("six", ex, dt, precision, True)]
+        print(f"launch plan with replicas, {ex}/{dt} {precision}: {replays} replays, {callbacks} callback nodes, {launches} launches")
+        assert replays == 3 and len(callbacks) == 1 and callbacks[0] >= 2, (ex, dt, precision, replays, callbacks)
+        close(planned, eager, ("planned vs eager", ex, dt, precision))
     close(out[("under_backward", "fp32")], out[("plain", "fp32")], "Adam under backward")
     for key in (("early_buckets", "fp32"), ("early_buckets", "bf16"), ("early_buckets_off", "fp32")):
         close(out[key], out[("plain", key[1])], key)

@@ -94,6 +94,66 @@ def test_two_rank_step_equals_accumulated_single_process(dev):
     assert err <= 1e-5, err
 
 
+def _six_worker(rank, port, q, planned):
+    """Six same-shape steps: issued from Python, or through ``train.planned_step`` (two eager, one recorded, three replayed
+    with the gloo collectives and their waits as callback nodes of the plan)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import tethys_speech_amd  # noqa: F401
+    from tethys_speech_amd import dist as D, optim, train, whisper
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    strat = D.DataParallelStrategy(rank, 2, backend="gloo", bucket_bytes=256 * 1024)
+    model = whisper.create_whisper_model("small", device=dev, precision="fp32", seed=11, **KW)
+    strat.broadcast_parameters(model.arena.p)
+    model.refresh_shadows()
+    opt = optim.Adam(1e-3)
+    if planned:
+        step = train.planned_step(strat, model, opt, "whisper", pipelined=True)
+        assert step.planned is not None
+    else:
+        step = lambda f, l: train.distributed_train_step(strat, model, (f, l), opt, pipelined=True)
+    rng = np.random.default_rng(70 + rank)
+    losses = []
+    for _ in range(6):
+        f = rng.standard_normal((2, 16, 48)).astype(np.float32)
+        l = rng.integers(0, 150, (2, 12)).astype(np.int32)
+        losses.append(float(step(torch.from_numpy(f).to(dev), torch.from_numpy(l).to(dev)).item()))
+    model.finish_late()
+    torch.cuda.synchronize()
+    info = None
+    if planned:
+        pl = [v["plan"] for v in step.planned._by_sig.values() if v.get("plan") is not None]
+        info = (step.planned.replays, [p_.callbacks for p_ in pl])
+    q.put((rank, model.arena.p.cpu().numpy(), losses, info))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_launch_plan_replays_the_exchange(dev):
+    """plan.host_call: a replayed step of a job with replicas issues its collectives from callback nodes.  Both ranks of the
+    planned job stay identical, and equal to the eager job (same data) up to the step's own atomics noise."""
+    res = {}
+    for planned in (False, True):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_six_worker, args=(r, port, q, planned)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        res[planned] = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p_ in procs:
+            p_.join(60)
+    (_, e0, le0, _), (_, e1, le1, _) = res[False]
+    (_, p0, lp0, i0), (_, p1, lp1, i1) = res[True]
+    assert np.array_equal(e0, e1) and np.array_equal(p0, p1), "replicas diverged"
+    assert le0 == le1 and lp0 == lp1
+    for replays, callbacks in (i0, i1):
+        assert replays == 3 and len(callbacks) == 1 and callbacks[0] >= 2, (replays, callbacks)
+    assert np.allclose(lp0, le0, rtol=1e-5, atol=1e-6), (lp0, le0)
+    assert np.abs(p0 - e0).max() / np.abs(e0).max() <= 1e-5
+
+
 def _ragged_worker(rank, port, q):
     """Step 1 is the short final batch of a pass (W:812-815 has no drop_remainder): rank 0 gets one sample,
     rank 1 none.  ADVICE r1 (train.py:22): the empty replica must issue the same bucket collectives."""
@@ -223,7 +283,9 @@ def test_two_rank_stable_wav2vec2_step_matches_oracle(dev):
 
 # ---- speech_jobs/wav2vec2_dist.py ("V:") on two replicas: loss / N, local global-norm clip before the exchange,
 # gradient SUM, per-variable clipnorm after it, Adam eps 1e-8 - against oracle.train_steps(n_replicas=2) in fp64
-def _v_worker(rank, port, q):
+def _v_worker(rank, port, q, planned=None, steps=4):
+    """``planned``: None = the step function called directly (the oracle comparison below); False / True = ``steps`` steps
+    through ``train.planned_step`` with launch plans off / on (plan.host_call: the collectives as callback nodes)."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -242,16 +304,49 @@ def _v_worker(rank, port, q):
     rng = np.random.default_rng(77)
     it = TW.V.batches(pool, 4)
     losses = []
-    for _ in range(4):
+    if planned is None:
+        step = lambda a_, n_: train.wav2vec2_train_step(strat, model, a_, n_, opt)
+    else:
+        train.USE_PLAN = bool(planned)
+        step = train.planned_step(strat, model, opt, "wav2vec2", pipelined=False)
+        assert (step.planned is not None) == bool(planned)
+    for _ in range(steps):
         a = next(it)
         neg = TW.V.sample_negative_indices(rng, 4, T, ocfg.num_negatives)
         sl = slice(2 * rank, 2 * rank + 2)
-        out = train.wav2vec2_train_step(strat, model, torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev),
-                                        torch.from_numpy(np.ascontiguousarray(neg[sl])).to(dev), opt)
+        out = step(torch.from_numpy(np.ascontiguousarray(a[sl])).to(dev), torch.from_numpy(np.ascontiguousarray(neg[sl])).to(dev))
         losses.append(float(out.item()))
     torch.cuda.synchronize()
-    q.put((rank, model.arena.p.cpu().numpy(), losses))
+    if planned:
+        pl = [v["plan"] for v in step.planned._by_sig.values() if v.get("plan") is not None]
+        q.put((rank, model.arena.p.cpu().numpy(), losses, (step.planned.replays, [p_.callbacks for p_ in pl])))
+    else:
+        q.put((rank, model.arena.p.cpu().numpy(), losses))
     torch.distributed.destroy_process_group()
+
+
+def test_two_rank_wav2vec2_launch_plan_replays_the_exchange(dev):
+    """The V: step with replicas (local clip, bucketed SUM, per-variable clipnorm, Adam) replayed from a launch plan."""
+    res = {}
+    for planned in (False, True):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_v_worker, args=(r, port, q, planned, 6)) for r in range(2)]
+        for p_ in procs:
+            p_.start()
+        res[planned] = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p_ in procs:
+            p_.join(60)
+    (_, e0, le0), (_, e1, le1) = res[False]
+    (_, p0, lp0, i0), (_, p1, lp1, i1) = res[True]
+    assert np.array_equal(e0, e1) and np.array_equal(p0, p1), "replicas diverged"
+    assert le0 == le1 and lp0 == lp1
+    for replays, callbacks in (i0, i1):
+        assert replays == 3 and len(callbacks) == 1 and callbacks[0] >= 2, (replays, callbacks)
+    assert np.allclose(lp0, le0, rtol=1e-4, atol=1e-5), (lp0, le0)
+    dp = np.abs(p0 - e0)   # (the step's own fp32 atomics make two eager runs differ in the last bits too)
+    assert float(np.median(dp)) <= 1e-6 and float((dp > 1e-4).mean()) <= 2e-3, (float(np.median(dp)), float(dp.max()))
 
 
 def test_two_rank_wav2vec2_step_matches_oracle(dev):

@@ -23,6 +23,8 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from .plan import WorkSlot, host_call
+
 
 def task_from_env(env=None) -> Tuple[str, int, int, int]:
     """-> (task_type, task_index, rank, world).  TF_CONFIG wins when it names a cluster
@@ -165,6 +167,24 @@ class DataParallelStrategy:
             t = self._stage[key] = torch.empty(n, dtype=dtype, device=like.device)
         return t
 
+    # fills and copies of the staging buffers: library launches on device tensors (a launch plan records them; torch's
+    # own fill_ / copy_ would run while recording and be missing from every replay)
+    @staticmethod
+    def _fill_zero(t):
+        if t.is_cuda:
+            from . import ops
+            ops.fill_zero(t)
+        else:
+            t.zero_()
+
+    @staticmethod
+    def _copy(dst, src):
+        if dst.is_cuda:
+            from . import ops
+            ops.copy(dst, src)
+        else:
+            dst.copy_(src)
+
     def _pack(self, src, dst):
         if src.is_cuda:
             from . import ops
@@ -221,11 +241,18 @@ class DataParallelStrategy:
         works = []
 
         def issue(fn, *a, **kw):
-            w = fn(*a, async_op=True, **kw)
+            # through plan.host_call: issued now and - while a launch plan records this step - a callback node of the plan;
+            # the Work lives in a slot that every replay refills (plan.WorkSlot)
+            slot = WorkSlot()
+
+            def call():
+                slot.work = fn(*a, async_op=True, **kw)
+            host_call(call)
             if self._serial:
-                w.wait()
+                slot.wait()
             else:
-                works.append(w)
+                works.append(slot)
+            return slot
 
         if self.exchange == "allreduce":
             if wire_dt == torch.float32:
@@ -242,9 +269,9 @@ class DataParallelStrategy:
             padded = per * N
             wire = self._buf((lo, hi, "wire"), padded, wire_dt, g)
             if padded > n:
-                wire[n:].zero_()
+                self._fill_zero(wire[n:])
             if wire_dt == torch.float32:
-                wire[:n].copy_(sl)
+                self._copy(wire[:n], sl)
             else:
                 self._pack(sl, wire[:n])
             shard = self._buf((lo, hi, "shard"), per, wire_dt, g)
@@ -254,18 +281,20 @@ class DataParallelStrategy:
                 post = lambda: self._unpack(wire, sl)
             else:  # mesh: piece j goes straight to rank j; fp32 sum of the N received pieces here
                 recv = self._buf((lo, hi, "recv"), padded, wire_dt, g)
-                w = dist.all_to_all_single(recv, wire, async_op=True)
+                w = issue(dist.all_to_all_single, recv, wire)
                 # The local fold below reads ``recv``: the exchange stream has to be ordered after the all-to-all.  Under
                 # RCCL ``Work.wait()`` IS that stream-order dependency (hipStreamWaitEvent on the current stream - here the
                 # exchange stream - against the collective's own stream; the host returns at once:
                 # tests/test_rccl_world1_gpu.py times the issue path behind 50 ms of queued device work).  gloo has no
                 # streams: there it blocks, as every gloo collective of this class does (``_serial``).
-                w.wait()
+                if not self._serial:
+                    works.remove(w)
+                    w.wait()
                 red = self._buf((lo, hi, "red"), per, torch.float32, g)
                 self._unpack(recv, red, nparts=N, part_stride=per)
                 full = self._buf((lo, hi, "full"), padded, torch.float32, g)
                 issue(dist.all_gather_into_tensor, full, red)
-                post = lambda: sl.copy_(full[:n])
+                post = lambda: self._copy(sl, full[:n])
         return works, post
 
     def _launch(self):

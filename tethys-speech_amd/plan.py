@@ -14,6 +14,13 @@ methods for the duration of the recording.  The plan keeps the event objects ali
 the same handles.  What a plan must NOT contain: device work issued by anything else (a torch kernel between two
 launches would run while recording and be missing from every replay) - the step code uses ``ops.fill_zero`` /
 ``ops.copy`` for its fills and copies, and tests/test_plan_gpu.py compares replayed steps with eager ones bit for bit.
+
+Replicas: the gradient exchange is issued through ``torch.distributed`` (RCCL), which the library cannot record.  Those
+calls go through ``host_call(fn)``: ``fn`` runs at once and, while a plan is recording, becomes a CALLBACK node - the
+replay calls it at the same place of the launch sequence, with the torch stream that was current when it was recorded
+(a collective is ordered after the current stream, ``Work.wait()`` orders the current stream after the collective).  A
+replayed step of an N-replica job is then the recorded launches plus one Python call per collective / wait
+(``DataParallelStrategy._exchange_body``), instead of ~255 ``ctypes`` launches.
 """
 from __future__ import annotations
 
@@ -26,6 +33,31 @@ from ._lib import check, lib
 
 SEED_STEP = 0x9E3779B97F4A7C15  # KernelBlocks._site_seed: the per-step stride of every dropout site's seed
 
+_recording = None   # the LaunchPlan recording on this thread (one at a time: tmi_plan_begin refuses a second)
+_CALLBACK = C.CFUNCTYPE(None)
+
+
+def host_call(fn):
+    """Run ``fn()`` now; while a plan is recording also make it a callback node of that plan (see the module docstring).
+    ``fn`` must be replayable: everything it touches lives in objects that outlive the step (buffers allocated once,
+    ``WorkSlot``s), and it returns nothing."""
+    plan = _recording
+    if plan is not None:
+        plan.add_callback(fn)
+    fn()
+
+
+class WorkSlot:
+    """The ``Work`` of a collective issued through ``host_call``: a replay puts its own Work object in the slot, and
+    ``wait()`` (itself a host call) waits for whichever is there."""
+    __slots__ = ("work",)
+
+    def __init__(self):
+        self.work = None
+
+    def wait(self):
+        host_call(lambda: self.work.wait())
+
 
 class LaunchPlan:
     def __init__(self):
@@ -34,6 +66,8 @@ class LaunchPlan:
         self._h = h
         self._keep = []       # events (and anything else) whose handles the plan refers to
         self.recorded = False
+        self.callbacks = 0
+        self._error = None    # an exception raised inside a callback node during the last replay
 
     def __del__(self):
         try:
@@ -42,6 +76,29 @@ class LaunchPlan:
                 self._h = None
         except Exception:
             pass
+
+    def add_callback(self, fn):
+        """``fn()`` becomes a node of the plan being recorded: called by every replay at this place of the sequence, with
+        the torch stream that is current NOW made current around it."""
+        if torch.cuda.is_available():
+            cur = torch.cuda.current_stream()
+            ctx = lambda: torch.cuda.stream(cur)
+        else:
+            ctx = contextlib.nullcontext
+
+        def node():
+            if self._error is not None:
+                return       # a previous node of this replay failed: issue nothing more (the caller raises after the replay)
+            try:
+                with ctx():
+                    fn()
+            except BaseException as e:   # (an exception cannot cross the C frames of the replay loop)
+                self._error = e
+
+        cb = _CALLBACK(node)
+        self._keep.append(cb)
+        self.callbacks += 1
+        check(lib().tmi_plan_note_callback(C.cast(cb, C.c_void_p)), "tmi_plan_note_callback")
 
     @contextlib.contextmanager
     def recording(self):
@@ -66,17 +123,25 @@ class LaunchPlan:
             keep.append(ev)
             L.tmi_plan_note_stream_wait(stream.cuda_stream, ev.cuda_event)
 
+        global _recording
         check(L.tmi_plan_begin(self._h), "tmi_plan_begin")
         Event.record, Event.wait = record, wait
+        _recording = self
         try:
             yield self
         finally:
+            _recording = None
             Event.record, Event.wait = rec0, wait0
             check(L.tmi_plan_end(self._h), "tmi_plan_end")
         self.recorded = True
 
     def replay(self, seed_delta=0, step_delta=0):
-        check(lib().tmi_plan_replay(self._h, seed_delta & 0xFFFFFFFFFFFFFFFF, step_delta), "tmi_plan_replay")
+        self._error = None
+        rc = lib().tmi_plan_replay(self._h, seed_delta & 0xFFFFFFFFFFFFFFFF, step_delta)
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+        check(rc, "tmi_plan_replay")
 
     @property
     def nodes(self):

@@ -84,15 +84,18 @@ def distributed_train_step(strategy, model, dist_inputs, optimizer, pipelined=Fa
     return strategy.reduce_sum(loss.clone())
 
 
-# Launch plans (plan.py): the step recorded once per batch shape and replayed from one C call.  On by default for a single
-# replica on a GPU (TMI_PLAN=0: every step issued from Python); with replicas the RCCL collectives are issued through
-# torch.distributed between the launches, which the plan does not record - those jobs stay eager.
+# Launch plans (plan.py): the step recorded once per batch shape and replayed from one C call.  On by default on a GPU
+# (TMI_PLAN=0: every step issued from Python).  With replicas the collectives are issued through torch.distributed between
+# the launches: they are callback nodes of the plan (plan.host_call in DataParallelStrategy._exchange_body), so a replayed
+# step of an N-replica job is one C call that comes back to Python once per collective / wait.  TMI_PLAN_REPLICAS=0 keeps
+# jobs with replicas eager.
 USE_PLAN = os.environ.get("TMI_PLAN", "1") != "0"
+PLAN_REPLICAS = os.environ.get("TMI_PLAN_REPLICAS", "1") != "0"
 
 
 def plan_ok(strategy, model):
-    return (USE_PLAN and strategy.world == 1 and not strategy.force_collectives and model.device.type == "cuda"
-            and not ADAM_UNDER_BACKWARD)
+    replicas = strategy.world > 1 or strategy.force_collectives
+    return (USE_PLAN and (PLAN_REPLICAS or not replicas) and model.device.type == "cuda" and not ADAM_UNDER_BACKWARD)
 
 
 def planned_step(strategy, model, optimizer, kind="whisper", pipelined=True):
