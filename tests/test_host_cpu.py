@@ -484,6 +484,10 @@ def test_no_valu_read_inside_an_mfma_hazard_window():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_hazards.py"), lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "0 candidate hazard(s) in" in r.stdout and " 0 code object" not in r.stdout
+    # second rule (round 5): no SGPR is read or written while a scalar load into it may still be in flight - the dK/dV
+    # kernel issues its mask loads by hand, and an asm output the compiler believed dead was handed to an address computation
+    # (a fault on the one shape whose register allocation put a pointer there)
+    assert "0 scalar-load destination(s) touched in flight" in r.stdout
 
 
 def test_launch_plan_callback_nodes_replay_in_order_and_raise():

@@ -558,7 +558,9 @@ def _decode_dropmask(dm, B, H, Tq, Tk):
                                                  (1, 4, 1500, 1500, 0, 0.1),
                                                  # key-split path (one query tile, >= 8 key tiles, workspace given): 3 ranges
                                                  # of 3 tiles / 4 ranges with a ragged last tile / the cross-attention shape
-                                                 (2, 2, 128, 520, 0, 0.0), (1, 3, 37, 1000, 0, 0.1), (8, 12, 100, 1500, 0, 0.1)])
+                                                 (2, 2, 128, 520, 0, 0.0), (1, 3, 37, 1000, 0, 0.1), (8, 12, 100, 1500, 0, 0.1),
+                                                 # one query tile, <= 2 key blocks: both backward passes in one launch
+                                                 (2, 3, 99, 99, 0, 0.1), (2, 2, 128, 256, 0, 0.1), (1, 2, 128, 128, 1, 0.1)])
 def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     ops = _ops()
     D = H * 64
@@ -611,6 +613,35 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     within(tag + " bwd dv", rel_err(dv, merge(vr.grad, Tk)), 1.5e-2)   # measured <= 4.7e-3
     within(tag + " bwd dk", rel_err(dk, merge(kr.grad, Tk)), 1.5e-2)   # measured <= 6.2e-3
     within(tag + " bwd dq", rel_err(dq, 0.5 * merge(qr.grad, Tq)), 1.5e-2)   # measured <= 5.9e-3
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk,mask,drop", [(2, 3, 100, 100, 1, 0.1), (8, 12, 99, 99, 0, 0.1), (1, 1, 31, 31, 1, 0.0),
+                                                 (2, 2, 128, 256, 0, 0.1), (2, 2, 100, 200, 0, 0.0), (1, 2, 128, 128, 1, 0.1)])
+def test_attn_bwd_one_launch_equals_the_two_passes(dev, B, H, Tq, Tk, mask, drop):
+    """Small problems (Tq <= 128, Tk <= 256: the decoder's self-attention, Wav2Vec2's) run both backward passes as ONE launch
+    (attn_bwd_small_kernel: the dK/dV blocks compute the row sums delta themselves, in the dQ pass's summation order).  The
+    result is bit for bit what the two separate launches (bwd_passes 1, then 2) write."""
+    ops = _ops()
+    D = H * 64
+    bf = torch.bfloat16
+    q, k, v = rnd((B, Tq, D), bf, dev, 60, 0.35), rnd((B, Tk, D), bf, dev, 61), rnd((B, Tk, D), bf, dev, 62)
+    do = rnd((B, Tq, D), bf, dev, 63)
+    o = torch.empty((B, Tq, D), dtype=bf, device=dev)
+    stats = torch.empty((B, H, Tq, 2), dtype=torch.float32, device=dev)
+    dmask = ops.attn_dropmask(dev, B, H, Tq, Tk) if drop > 0 else None
+    Q, K, V, O = (q, 0, Tq * D, D), (k, 0, Tk * D, D), (v, 0, Tk * D, D), (o, 0, Tq * D, D)
+    ops.attn_fwd(Q, K, V, O, stats, B, H, Tq, Tk, mask, dropout_p=drop, dropout_seed=77, drop_mask=dmask)
+    res = []
+    for passes in ((0,), (1, 2)):
+        dq, dk, dv = torch.full_like(q, 7.0), torch.full_like(k, 7.0), torch.full_like(v, 7.0)
+        delta = torch.zeros((B, H, Tq), dtype=torch.float32, device=dev)
+        for ps in passes:
+            ops.attn_bwd(Q, K, V, O, stats, (do, 0, Tq * D, D), (dq, 0, Tq * D, D), (dk, 0, Tk * D, D), (dv, 0, Tk * D, D), delta,
+                         B, H, Tq, Tk, mask, dropout_p=drop, dropout_seed=77, drop_mask=dmask, passes=ps)
+        torch.cuda.synchronize()
+        res.append((dq, dk, dv, delta))
+    for name, a, b in zip(("dq", "dk", "dv", "delta"), res[0], res[1]):
+        assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

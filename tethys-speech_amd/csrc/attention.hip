@@ -312,6 +312,7 @@ struct AttnP {
   // ([B*H][ksplit][Tq][64] fp32, then for the forward [B*H][ksplit][Tq][2] = (m, l)) and a combine kernel folds them.
   int ksplit;
   float* part;
+  int nq;  // attn_bwd_small_kernel: blocks [0, nq) of a pair run the dQ pass
 };
 
 // ABL (diagnostics, TMI_ATTN_ABL): 1 = no softmax arithmetic (p = s), 2 = no second product, 3 = no staging after the
@@ -536,28 +537,28 @@ __global__ __launch_bounds__(256, OCC) void attn_fwd_kernel(const AttnP P) {
 }
 
 // ------------------------------------------------------------------ dQ pass (owner = query)
-template <bool DROP, int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
+// block -> (block of the pair, head, batch): the XCD-aware 1-D grid of pick_grid, or the plain 3-D one
+__device__ __forceinline__ void block_coords(const AttnP& P, int& bx, int& head, int64_t& b) {
+  if (P.gx > 0) {
+    const int L = (int)blockIdx.x, r = L >> 3;
+    const int bh = (r / P.gx) * 8 + (L & 7);
+    bx = r % P.gx;
+    head = bh % (int)P.d.H;
+    b = bh / (int)P.d.H;
+  } else {
+    bx = (int)blockIdx.x;
+    head = (int)blockIdx.y;
+    b = (int64_t)blockIdx.z;
+  }
+}
+
+template <bool DROP>
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnP& P, const int bx, const int head, const int64_t b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K img | V img]
   const tmi_attn_desc& d = P.d;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
-  int bx_, head_;
-  int64_t b_;
-  if (P.gx > 0) {
-    const int L = (int)blockIdx.x, r = L >> 3;
-    const int bh = (r / P.gx) * 8 + (L & 7);
-    bx_ = r % P.gx;
-    head_ = bh % (int)P.d.H;
-    b_ = bh / (int)P.d.H;
-  } else {
-    bx_ = (int)blockIdx.x;
-    head_ = (int)blockIdx.y;
-    b_ = (int64_t)blockIdx.z;
-  }
-  const int bx = bx_, head = head_;
-  const int64_t b = b_;
   const int ks = P.ksplit, qt = bx / ks, sp = bx - qt * ks;
   const int q = qt * 128 + wave * 32 + c;
   const int Tq = (int)d.Tq, Tk = (int)d.Tk;
@@ -673,30 +674,26 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
   store_owner(dq, dqb, d.dq_st, q, Tq, h, P.dq_scale * P.sscale);
 }
 
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dq_kernel(const AttnP P) {
+  int bx, head;
+  int64_t b;
+  block_coords(P, bx, head, b);
+  attn_bwd_dq_body<DROP>(P, bx, head, b);
+}
+
 // ------------------------------------------------------------------ dK/dV pass (owner = key)
 constexpr int NCONST = 4;  // per streamed query row: m, 1/l, delta (/ keep_scale with dropout), -(m + log2 l)
-template <bool DROP, int OCC>
-__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
+// LOCAL_DELTA: delta = rowsum(dO . O) of the streamed query rows is
+// computed here (in the dQ pass's summation order) instead of read from d.delta - the pass then depends on nothing the dQ
+// pass writes, and the two can share one launch (attn_bwd_small_kernel).
+template <bool DROP, bool LOCAL_DELTA>
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnP& P, const int bx, const int head, const int64_t b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][Q img | dO img] then [2][NCONST][64] floats
   const tmi_attn_desc& d = P.d;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 31, h = lane >> 5;
-  int bx_, head_;
-  int64_t b_;
-  if (P.gx > 0) {
-    const int L = (int)blockIdx.x, r = L >> 3;
-    const int bh = (r / P.gx) * 8 + (L & 7);
-    bx_ = r % P.gx;
-    head_ = bh % (int)P.d.H;
-    b_ = bh / (int)P.d.H;
-  } else {
-    bx_ = (int)blockIdx.x;
-    head_ = (int)blockIdx.y;
-    b_ = (int64_t)blockIdx.z;
-  }
-  const int bx = bx_, head = head_;
-  const int64_t b = b_;
   // Which key a lane owns is free (its K / V rows are gathered and its dK / dV rows scattered row by row anyway).  With
   // dropout a wave owns the 32 keys of ONE word of the stored mask - key tile 2 blockIdx.x + (wave >> 1), forward lane half
   // wave & 1 - with lane c on bit c of the word (bit j / 16 + j = even / odd key of pair j, see mask_pos): the word of a
@@ -715,6 +712,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   const bf16_t* kb = reinterpret_cast<const bf16_t*>(d.k) + b * d.k_sb + head * HD;
   const bf16_t* vb = reinterpret_cast<const bf16_t*>(d.v) + b * d.v_sb + head * HD;
   const bf16_t* dob = reinterpret_cast<const bf16_t*>(d.d_o) + b * d.do_sb + head * HD;
+  const bf16_t* ob = reinterpret_cast<const bf16_t*>(d.o) + b * d.o_sb + head * HD;
   const float* stats = d.stats + (b * d.H + head) * Tq * 2;
   const float* deltas = d.delta + (b * d.H + head) * Tq;
   float* rowc_base = reinterpret_cast<float*>(smem + 4 * IMG);
@@ -754,7 +752,24 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
     x0 = 0.f;
     x1 = 1.f;
     if (qi < Tq) {
-      x0 = cwhich == 2 ? deltas[qi] : stats[qi * 2];
+      if (LOCAL_DELTA && cwhich == 2) {
+        // (the dQ pass's order: lane half h sums chunks 16 kk + 8 h + j in (kk, j) order, then the halves are added)
+        const bf16_t* orow = ob + (int64_t)qi * d.o_st;
+        const bf16_t* drow = dob + (int64_t)qi * d.do_st;
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 ov = *reinterpret_cast<const bf16x8*>(orow + kk * 16 + hh * 8);
+            const bf16x8 dv_ = *reinterpret_cast<const bf16x8*>(drow + kk * 16 + hh * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[hh] += (float)dv_[j] * (float)ov[j];
+          }
+        x0 = part[0] + part[1];
+      } else {
+        x0 = cwhich == 2 ? deltas[qi] : stats[qi * 2];
+      }
       x1 = stats[qi * 2 + 1];
     }
   };
@@ -774,17 +789,20 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
     rowc_base[threadIdx.x] = make_const(x0, x1);
   }
   u32x16 mk0, mk1, mk2, mk3;  // select masks of the 32-row halves: (mk0, mk1) rows 0..31, (mk2, mk3) rows 32..63; 32 SGPRs live at a time
+  // (the two warm-up dwords land in registers of their own that stay allocated until wait_masks0: a scalar load writes its
+  // destination whenever it returns, so a destination the compiler believes dead - and hands to an address computation - would
+  // be overwritten behind its back)
+  uint32_t warm0 = 0, warm1 = 0;
   auto issue_masks0 = [&](int tile) {  // first half of a tile + one dword of each line of the second half (scalar-cache warm-up)
     const uint32_t* mt = mwave + tile * 64;
-    uint32_t t0_, t1_;
     asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0"
-                 : "=&s"(mk0), "=&s"(mk1), "=&s"(t0_), "=&s"(t1_) : "s"(mt) : "memory");
+                 : "=&s"(mk0), "=&s"(mk1), "=&s"(warm0), "=&s"(warm1) : "s"(mt) : "memory");
   };
   auto issue_masks1 = [&](int tile) {
     const uint32_t* mt = mwave + tile * 64;
     asm volatile("s_load_dwordx16 %0, %2, 0x80\n\ts_load_dwordx16 %1, %2, 0xc0" : "=&s"(mk2), "=&s"(mk3) : "s"(mt) : "memory");
   };
-  auto wait_masks0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk0), "+s"(mk1)::"memory"); };
+  auto wait_masks0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk0), "+s"(mk1), "+s"(warm0), "+s"(warm1)::"memory"); };
   auto wait_masks1 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mk2), "+s"(mk3)::"memory"); };
   if constexpr (DROP) issue_masks0(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -888,6 +906,26 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   bf16_t* dvb = reinterpret_cast<bf16_t*>(d.dv) + b * d.dv_sb + head * HD;
   store_owner(dk, dkb, d.dk_st, key, Tk, h, DROP ? P.sscale * P.keep_scale : P.sscale);
   store_owner(dv, dvb, d.dv_st, key, Tk, h, DROP ? P.keep_scale : 1.0f);
+}
+
+template <bool DROP, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
+  int bx, head;
+  int64_t b;
+  block_coords(P, bx, head, b);
+  attn_bwd_dkv_body<DROP, false>(P, bx, head, b);
+}
+
+// Both backward passes of a SMALL problem in one launch (the decoder's self-attention, Wav2Vec2's: one query tile, one or two
+// key blocks - each pass is a 10-13 us kernel that is mostly launch latency): blocks [0, P.nq) of a (batch, head) pair run
+// the dQ pass, the rest the dK/dV pass with the row sums delta computed locally.  Plain 3-D grid.
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnP P) {
+  const int bx = (int)blockIdx.x;
+  if (bx < P.nq)
+    attn_bwd_dq_body<DROP>(P, bx, (int)blockIdx.y, (int64_t)blockIdx.z);
+  else
+    attn_bwd_dkv_body<DROP, true>(P, bx - P.nq, (int)blockIdx.y, (int64_t)blockIdx.z);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1065,6 +1103,19 @@ static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream) {
   }
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
+  P.nq = 0;
+  // one query tile against one or two key blocks (decoder self-attention, Wav2Vec2): each pass is a 10-13 us kernel, mostly
+  // launch latency, so both go out as ONE launch (TMI_ATTN_BWD_FUSE=0: two)
+  static const int fuse = [] { const char* e = getenv("TMI_ATTN_BWD_FUSE"); return e ? atoi(e) : 1; }();
+  if (fuse && do_dq && do_dkv && P.ksplit == 1 && dp->Tq <= 128 && dp->Tk <= 256) {
+    P.gx = 0;
+    P.nq = 1;
+    const dim3 g((unsigned)(P.nq + (dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
+    const size_t lds = 4 * IMG + 2 * NCONST * 64 * sizeof(float);
+    if (P.drop_thr) hipLaunchKernelGGL((attn_bwd_small_kernel<true>), g, dim3(256), lds, s, P);
+    else hipLaunchKernelGGL((attn_bwd_small_kernel<false>), g, dim3(256), lds, s, P);
+    return tmi_check_launch("tmi_attn_bwd(small)");
+  }
   if (do_dq) {
   dim3 gq = pick_grid(P, (unsigned)((dp->Tq + 127) / 128 * P.ksplit));
   static const int qocc = [] { const char* e = getenv("TMI_ATTN_DQ_OCC"); return e ? atoi(e) : 0; }();

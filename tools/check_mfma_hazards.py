@@ -8,6 +8,11 @@ or >= 18 (f32 32x32x2: 16-pass) wait states; the next MFMA taking it whole as C 
 C or an A / B read needs the full distance.  Every instruction issues >= 1 state, `s_nop N` N + 1; we count conservatively
 (1 per instruction, MFMAs 1: the real issue cost is higher), so a report here means "look", not "broken".
 
+Second rule (round 5, the dK/dV kernel's hand-issued mask loads): a scalar load writes its destination whenever it returns,
+so between an `s_load_*` and the next `s_waitcnt lgkmcnt(0)` NOTHING may read or write its destination SGPRs - a destination
+the compiler believes dead (an unused asm output) gets handed to something else and is then overwritten behind its back; one
+it copies or spills early holds stale data.  hipcc keeps this for its own loads; the asm-issued ones are checked here.
+
 usage: check_mfma_hazards.py [libtethys_mi.so]   (exit code 1 if a candidate is found)"""
 import os, re, subprocess, sys
 
@@ -15,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tethys-speech_amd", "libtethys_mi.so")
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 NEED = {"v_mfma_f32_32x32x16_bf16": 12, "v_mfma_f32_32x32x2_f32": 18, "v_mfma_f32_16x16x32_bf16": 8, "v_mfma_f32_16x16x4_f32": 10}
-KERNELS = re.compile(r"attn_(fwd|bwd_dq|bwd_dkv)_kernel|gemm_p8_kernel|gemm_fast_kernel|gemm_f32_kernel")
+KERNELS = re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|bwd_small)_kernel|gemm_p8_kernel|gemm_fast_kernel|gemm_f32_kernel")
 
 
 def regs(tok):
@@ -94,15 +99,65 @@ def scan(asm_lines):
     return bad
 
 
+def sregs(tok):
+    out = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b", tok):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def scan_scalar_loads(asm_lines):
+    """[(kernel, load, offending instruction)]: an SGPR touched while a scalar load into it may still be in flight."""
+    bad = []
+    kernel, flight = None, []   # flight: [(dest regs, load text)]
+    for line in asm_lines:
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            kernel = m.group(1) if KERNELS.search(m.group(1)) else None
+            flight = []
+            continue
+        if kernel is None:
+            continue
+        ins = line.split("//")[0].strip()
+        if not ins:
+            continue
+        parts = ins.split(None, 1)
+        op, args = parts[0], (parts[1] if len(parts) > 1 else "")
+        if op == "s_waitcnt":
+            if "lgkmcnt(0)" in args:
+                flight = []
+            continue
+        touched = sregs(args)
+        for dst, text in flight:
+            if touched & dst:
+                bad.append((kernel, text, ins))
+        if op.startswith("s_load_") or op.startswith("s_buffer_load_"):
+            flight.append((sregs(args.split(",")[0]), ins))
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+            flight = []
+    return bad
+
+
 def main():
     objs = extract_bundles(lib)
     if not objs:
         print("no gfx950 code object found in", lib)
         return 2
-    total = []
+    total, sl = [], []
     for o in objs:
         asm = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", o], capture_output=True, text=True).stdout.split("\n")
         total += scan(asm)
+        sl += scan_scalar_loads(asm)
+    seen_sl = set()
+    for k, ld, ins in sl:
+        key = (k[:60], ld, ins)
+        if key not in seen_sl:
+            seen_sl.add(key)
+            print(f"{k[:70]}\n    {ld}\n    destination touched before lgkmcnt(0): {ins}")
+    print(f"{len(seen_sl)} scalar-load destination(s) touched in flight")
     seen = set()
     for k, mf, ins, age, need in total:
         key = (k[:60], mf, ins)
@@ -111,7 +166,7 @@ def main():
         seen.add(key)
         print(f"{k[:70]}\n    {mf}\n    read {age} states later (needs {need}): {ins}")
     print(f"{len(seen)} candidate hazard(s) in {len(objs)} code object(s)")
-    return 1 if seen else 0
+    return 1 if (seen or seen_sl) else 0
 
 
 if __name__ == "__main__":
