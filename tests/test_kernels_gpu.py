@@ -159,9 +159,13 @@ def test_gemm_kbatch_splitk(dev):
         assert rel_err(dW, ref) <= 2e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(800, 768, 768), (333, 200, 448), (64, 64, 64), (130, 72, 1024), (800, 768, 576)])
+@pytest.mark.parametrize("M,N,K", [(800, 768, 768), (333, 200, 448), (64, 64, 64), (130, 72, 1024), (800, 768, 576),
+                                   # CFG 14 (257..512 tiles, K >= 1024: two workgroups per CU on 2-stage rings): Whisper-large's
+                                   # decoder shapes, an odd trip count (K = 1088: 17 tiles) with ragged edges
+                                   (800, 1280, 1280), (800, 1280, 5120), (790, 1300, 1088)])
 def test_gemm_k_groups_inside_the_workgroup(dev, M, N, K):
-    """Grids of at most one 64x64 tile per CU with K % 64 == 0 run two K-groups of four waves (gemm_fast.hip CFG 13): group g
+    """Grids of at most one 64x64 tile per CU with K % 64 == 0 run two K-groups of four waves (gemm_fast.hip CFG 13; CFG 14 up
+    to two tiles per CU when K >= 1024): group g
     multiplies K-tiles g, g + 2, ... and the partial accumulators meet in LDS.  Odd and even trip counts (K = 576: 9 tiles,
     K = 64: one tile, the second group idle), ragged edges, the whole epilogue (bias, saved pre-activation, GELU, residual),
     and the qkv-dgrad form whose reduction runs over three K batches."""

@@ -653,7 +653,10 @@ template <> struct Cfg<12> { static constexpr int BM = 64, BN = 64, WM = 32, WN 
 // six K-tiles in flight matter more still (M 800, N 768, K 768, cold weights: 13.5 us on CFG 11, 9.4 on CFG 12, 8.9 here).
 // K % 64 == 0 only (no tail zeroing).
 template <> struct Cfg<13> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 4; static constexpr bool SPEC = false; };
-template <int CFG> constexpr int kKG = CFG == 13 ? 2 : 1;
+// CFG 14: CFG 13's two K-groups on 2-stage rings (64 KiB: TWO workgroups per CU) - for 64x64 grids of more than one workgroup
+// per CU, where CFG 13's 128 KiB would run a second, nearly empty round (Whisper-large's decoder: [800, 1280] = 260 tiles).
+template <> struct Cfg<14> { static constexpr int BM = 64, BN = 64, WM = 32, WN = 32, NSTAGE = 2; static constexpr bool SPEC = false; };
+template <int CFG> constexpr int kKG = (CFG == 13 || CFG == 14) ? 2 : 1;
 template <int CFG> constexpr bool kRegStage = CFG >= 7 && CFG <= 9;
 
 // Split-K through the workspace: every split runs the ordinary (non-atomic) epilogue into its own
@@ -849,7 +852,7 @@ void gemm_fast_kernel(const FastParams P) {
         buf ^= 1;
       }
     }
-  } else if constexpr (NSTAGE > 2 && !K::SPEC && ABL == 0) {
+  } else if constexpr ((NSTAGE > 2 || kKG<CFG> > 1) && !K::SPEC && ABL == 0) {
     // Deep ring for latency-bound problems (one small workgroup per CU, nothing else to hide the
     // DMA round trip behind): tiles t+1 .. t+NSTAGE-1 are in flight while tile t is multiplied.
     // Counted wait: each wave issues LPT LDS-DMA instructions per tile, in tile order, so
@@ -1749,6 +1752,7 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
   if (force == 12 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
   if (force == 13 && d.splitk <= 1) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
   if (force == 15 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
+  if (force == 16 && d.splitk <= 1 && d.K % 64 == 0) return launch_cfg<TC, A_KS, B_KS, 14>(d, stream);
   if (small) {
     // measured (tools/gemm_small.py, M = 800): four waves of 32x32 beat two of 32x64 wherever the grid is
     // at most one workgroup per CU (N 768, K 768: 12.3 -> 9.1 us) and tie elsewhere; the 4-stage ring adds
@@ -1759,6 +1763,11 @@ int launch_fast(const tmi_gemm_desc& d, hipStream_t stream) {
       // (tools/gemm_small2.py, M 800 N 768: K 3072 22.9 -> 17.4 us, K 768 9.2 -> 8.7 us; a third group adds nothing)
       static const int no_kg = [] { const char* e = getenv("TMI_GEMM_NO_KGROUPS"); return e ? atoi(e) : 0; }();
       if (!no_kg && tiles64 <= 256 && d.K % 64 == 0 && d.K * d.kbatch >= 512) return launch_cfg<TC, A_KS, B_KS, 13>(d, stream);
+      // more than one workgroup per CU, up to two: the K-groups on 2-stage rings (Whisper-large's decoder, [800, 1280]:
+      // K 1280 16.0 -> 14.8 us, K 5120 50.6 -> 41.1 us; tools/gemm_large_dec_probe.py.  TMI_GEMM_KG2=0: CFG 11)
+      static const int kg2 = [] { const char* e = getenv("TMI_GEMM_KG2"); return e ? atoi(e) : 1024; }();
+      if (!no_kg && kg2 > 0 && tiles64 > 256 && tiles64 <= 512 && d.K % 64 == 0 && d.K * d.kbatch >= kg2)
+        return launch_cfg<TC, A_KS, B_KS, 14>(d, stream);
       if (tiles64 <= 256 && d.K * d.kbatch >= 1536) return launch_cfg<TC, A_KS, B_KS, 12>(d, stream);
       return launch_cfg<TC, A_KS, B_KS, 11>(d, stream);
     }
