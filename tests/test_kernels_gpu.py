@@ -564,7 +564,8 @@ def _decode_dropmask(dm, B, H, Tq, Tk):
                                                  # of 3 tiles / 4 ranges with a ragged last tile / the cross-attention shape
                                                  (2, 2, 128, 520, 0, 0.0), (1, 3, 37, 1000, 0, 0.1), (8, 12, 100, 1500, 0, 0.1),
                                                  # one query tile, <= 2 key blocks: both backward passes in one launch
-                                                 (2, 3, 99, 99, 0, 0.1), (2, 2, 128, 256, 0, 0.1), (1, 2, 128, 128, 1, 0.1)])
+                                                 (2, 3, 99, 99, 0, 0.1), (2, 2, 128, 256, 0, 0.1), (1, 2, 128, 128, 1, 0.1),
+                                                 (2, 2, 249, 249, 0, 0.1), (1, 2, 256, 256, 1, 0.0)])
 def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
     ops = _ops()
     D = H * 64
@@ -620,9 +621,10 @@ def test_flash_attention(dev, B, H, Tq, Tk, mask, drop):
 
 
 @pytest.mark.parametrize("B,H,Tq,Tk,mask,drop", [(2, 3, 100, 100, 1, 0.1), (8, 12, 99, 99, 0, 0.1), (1, 1, 31, 31, 1, 0.0),
-                                                 (2, 2, 128, 256, 0, 0.1), (2, 2, 100, 200, 0, 0.0), (1, 2, 128, 128, 1, 0.1)])
+                                                 (2, 2, 128, 256, 0, 0.1), (2, 2, 100, 200, 0, 0.0), (1, 2, 128, 128, 1, 0.1),
+                                                 (4, 12, 249, 249, 0, 0.1), (1, 2, 256, 256, 1, 0.0), (1, 2, 200, 130, 0, 0.1)])
 def test_attn_bwd_one_launch_equals_the_two_passes(dev, B, H, Tq, Tk, mask, drop):
-    """Small problems (Tq <= 128, Tk <= 256: the decoder's self-attention, Wav2Vec2's) run both backward passes as ONE launch
+    """Small problems (Tq <= 256, Tk <= 256: the decoder's self-attention, Wav2Vec2's) run both backward passes as ONE launch
     (attn_bwd_small_kernel: the dK/dV blocks compute the row sums delta themselves, in the dQ pass's summation order).  The
     result is bit for bit what the two separate launches (bwd_passes 1, then 2) write."""
     ops = _ops()

@@ -916,8 +916,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(const AttnP P) {
   attn_bwd_dkv_body<DROP, false>(P, bx, head, b);
 }
 
-// Both backward passes of a SMALL problem in one launch (the decoder's self-attention, Wav2Vec2's: one query tile, one or two
-// key blocks - each pass is a 10-13 us kernel that is mostly launch latency): blocks [0, P.nq) of a (batch, head) pair run
+// Both backward passes of a SMALL problem in one launch (the decoder's self-attention, Wav2Vec2's: at most two query blocks
+// and two key blocks - each pass is a 10-13 us kernel that is mostly launch latency): blocks [0, P.nq) of a (batch, head) pair run
 // the dQ pass, the rest the dK/dV pass with the row sums delta computed locally.  Plain 3-D grid.
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_small_kernel(const AttnP P) {
@@ -1104,12 +1104,12 @@ static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream) {
   P.ksplit = pick_ksplit(*dp);
   P.part = reinterpret_cast<float*>(dp->workspace);
   P.nq = 0;
-  // one query tile against one or two key blocks (decoder self-attention, Wav2Vec2): each pass is a 10-13 us kernel, mostly
-  // launch latency, so both go out as ONE launch (TMI_ATTN_BWD_FUSE=0: two)
+  // one or two query blocks against one or two key blocks (decoder self-attention, Wav2Vec2 at 2 s and 5 s clips): each pass
+  // is a 10-13 us kernel, mostly launch latency, so both go out as ONE launch (TMI_ATTN_BWD_FUSE=0: two)
   static const int fuse = [] { const char* e = getenv("TMI_ATTN_BWD_FUSE"); return e ? atoi(e) : 1; }();
-  if (fuse && do_dq && do_dkv && P.ksplit == 1 && dp->Tq <= 128 && dp->Tk <= 256) {
+  if (fuse && do_dq && do_dkv && P.ksplit == 1 && dp->Tq <= 256 && dp->Tk <= 256) {
     P.gx = 0;
-    P.nq = 1;
+    P.nq = (int)((dp->Tq + 127) / 128);
     const dim3 g((unsigned)(P.nq + (dp->Tk + 127) / 128), (unsigned)dp->H, (unsigned)dp->B);
     const size_t lds = 4 * IMG + 2 * NCONST * 64 * sizeof(float);
     if (P.drop_thr) hipLaunchKernelGGL((attn_bwd_small_kernel<true>), g, dim3(256), lds, s, P);
