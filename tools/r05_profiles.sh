@@ -50,6 +50,6 @@ python3 tools/gemm_f32_probe.py > $O/gemm_f32_probe.txt 2>&1 || true
 python3 tools/attn_bench.py > $O/attn_bench.txt 2>&1 || true
 ATTN_DROPOUT=0.1 python3 tools/attn_bench.py >> $O/attn_bench.txt 2>&1 || true
 python3 tools/ln_bench.py > $O/ln_bench.txt 2>&1 || true
-TMI_GEMM_CFG=14 TMI_GEMM_P8_PERSIST=0 TMI_GEMM_DBG=16 python3 tools/p8_stamps.py > $O/p8_stamps.txt 2>&1 || true
+# (tools/p8_stamps.py needs a library built with `make EXPERIMENTS=1`: the stamps are compiled out of the shipped one)
 echo "all done"
 ls $O
