@@ -204,10 +204,16 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     nrs = rstd[row];
   }
   for (; row < rows; row += step) {
-    float xv[E], dv[E], old[E];
+    // Rows of three chunks and more (C > 1024 in bf16: Whisper-large's 1280): the old dx stays in its raw registers until it
+    // is added (its prefetch for the next row is issued after that, below) - unpacked at the top it is E more live floats,
+    // and the emitting form spilled 33 registers to scratch (12000 x 1280: 50.6 us with the masked copy).
+    constexpr bool LATE_OLD = NCH >= 3;
+    float xv[E], dv[E], old[LATE_OLD ? 1 : E];
     IO::unpack(nx, xv);
     IO::unpack(ndy, dv);
-    if (accumulate_dx) IO::unpack(nold, old);
+    if constexpr (!LATE_OLD) {
+      if (accumulate_dx) IO::unpack(nold, old);
+    }
     // (the LayerNorm's output went through Dropout in the forward: its gradient is the masked, rescaled dy)
     if (dy_thr) drop_row<IO>(dv, dy_key, (uint32_t)row, lane, dy_thr, dy_scale);
     const float mu = nmu, rs = nrs;
@@ -215,7 +221,9 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     if (nr < rows) {
       IO::load_raw(x + nr * C, C, lane, nx);
       IO::load_raw(dy + nr * C, C, lane, ndy);
-      if (accumulate_dx) IO::load_raw(dx + nr * C, C, lane, nold);
+      if constexpr (!LATE_OLD) {
+        if (accumulate_dx) IO::load_raw(dx + nr * C, C, lane, nold);
+      }
       nmu = mean[nr];
       nrs = rstd[nr];
     }
@@ -238,12 +246,20 @@ __global__ __launch_bounds__(64 * LNB_WAVES) void ln_bwd_kernel(const T* __restr
     s1 = wave_sum(s1) * invC;
     s2 = wave_sum(s2) * invC;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float r = rs * (dv[e] * g[e] - s1 - xv[e] * s2);
-      if (accumulate_dx) r += old[e];
-      dv[e] = r;
+    for (int j = 0; j < NCH; ++j) {
+      const T* oe = reinterpret_cast<const T*>(&nold[j]);
+#pragma unroll
+      for (int i = 0; i < IO::VEC; ++i) {
+        const int e = j * IO::VEC + i;
+        float r = rs * (dv[e] * g[e] - s1 - xv[e] * s2);
+        if (accumulate_dx) r += LATE_OLD ? to_f32(oe[i]) : old[e];
+        dv[e] = r;
+      }
     }
     IO::store(dx + row * C, C, lane, dv);
+    if constexpr (LATE_OLD) {
+      if (accumulate_dx && nr < rows) IO::load_raw(dx + nr * C, C, lane, nold);
+    }
     if constexpr (EMIT) {
       if (masked && drop_thr) {
         const tmi_rowkey rk = tmi_row_key(drop_key, (uint32_t)row);
