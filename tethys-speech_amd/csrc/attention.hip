@@ -1039,15 +1039,26 @@ static int tmi_attn_fwd_impl(const tmi_attn_desc* dp, void* stream) {
   P.part = reinterpret_cast<float*>(dp->workspace);
   dim3 grid = pick_grid(P, (unsigned)((dp->Tq + 127) / 128 * P.ksplit));
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  // (workgroups per CU: 2 with dropout, 3 without - measured, tools/ab_attn.sh; the other occupancies (TMI_ATTN_FWD_OCC,
+  // ..._DQ_OCC, ..._DKV_OCC: they spill) and the ablation kernels are built with `make EXPERIMENTS=1` only)
+#ifdef TMI_ATTN_EXPERIMENTS
   static const int focc = [] { const char* e = getenv("TMI_ATTN_FWD_OCC"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int focc = 0;
+#endif
   if (P.drop_thr) {
+#ifdef TMI_ATTN_EXPERIMENTS
     if (focc == 4) hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), grid, dim3(256), 4 * IMG, hs, P);
     else if (focc == 5) hipLaunchKernelGGL((attn_fwd_kernel<true, 5>), grid, dim3(256), 4 * IMG, hs, P);
-    else if (focc == 2) hipLaunchKernelGGL((attn_fwd_kernel<true, 2>), grid, dim3(256), 4 * IMG, hs, P);
-    else hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
+    else if (focc == 3) hipLaunchKernelGGL((attn_fwd_kernel<true, 3>), grid, dim3(256), 4 * IMG, hs, P);
+    else
+#endif
+    hipLaunchKernelGGL((attn_fwd_kernel<true, DROP_OCC>), grid, dim3(256), 4 * IMG, hs, P);
   } else if (focc == 4 || focc == 5) {
+#ifdef TMI_ATTN_EXPERIMENTS
     if (focc == 4) hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), grid, dim3(256), 4 * IMG, hs, P);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 5>), grid, dim3(256), 4 * IMG, hs, P);
+#endif
   } else {
 #ifdef TMI_ATTN_EXPERIMENTS  // ablation builds of the forward (diagnostics; not in the shipped library)
     static const int abl = [] { const char* e = getenv("TMI_ATTN_ABL"); return e ? atoi(e) : 0; }();
@@ -1118,15 +1129,24 @@ static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream) {
   }
   if (do_dq) {
   dim3 gq = pick_grid(P, (unsigned)((dp->Tq + 127) / 128 * P.ksplit));
+#ifdef TMI_ATTN_EXPERIMENTS
   static const int qocc = [] { const char* e = getenv("TMI_ATTN_DQ_OCC"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int qocc = 0;
+#endif
   if (P.drop_thr) {
+#ifdef TMI_ATTN_EXPERIMENTS
     if (qocc == 3) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 3>), gq, dim3(256), 4 * IMG, s, P);
     else if (qocc == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 4>), gq, dim3(256), 4 * IMG, s, P);
     else if (qocc == 5) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, 5>), gq, dim3(256), 4 * IMG, s, P);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
+    else
+#endif
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true, DQ_DROP_OCC>), gq, dim3(256), 4 * IMG, s, P);
   } else if (qocc == 4 || qocc == 5) {
+#ifdef TMI_ATTN_EXPERIMENTS
     if (qocc == 4) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 4>), gq, dim3(256), 4 * IMG, s, P);
     else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 5>), gq, dim3(256), 4 * IMG, s, P);
+#endif
   } else
     hipLaunchKernelGGL((attn_bwd_dq_kernel<false, 3>), gq, dim3(256), 4 * IMG, s, P);
   if (P.ksplit > 1) {
@@ -1141,16 +1161,16 @@ static int tmi_attn_bwd_impl(const tmi_attn_desc* dp, void* stream) {
   if (!do_dkv) return TMI_OK;
   P.ksplit = 1;
   dim3 gk = pick_grid(P, (unsigned)((dp->Tk + 127) / 128));
-  static const int kocc = [] { const char* e = getenv("TMI_ATTN_DKV_OCC"); return e ? atoi(e) : 0; }();
   const size_t klds = 4 * IMG + 2 * NCONST * 64 * sizeof(float);
-  if (P.drop_thr) {
-    if (kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 3>), gk, dim3(256), klds, s, P);
-    else if (kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 4>), gk, dim3(256), klds, s, P);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), klds, s, P);
-  } else {
-    if (kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 3>), gk, dim3(256), klds, s, P);
-    else if (kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 4>), gk, dim3(256), klds, s, P);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, dim3(256), klds, s, P);
-  }
+#ifdef TMI_ATTN_EXPERIMENTS
+  static const int kocc = [] { const char* e = getenv("TMI_ATTN_DKV_OCC"); return e ? atoi(e) : 0; }();
+  if (P.drop_thr && kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 3>), gk, dim3(256), klds, s, P);
+  else if (P.drop_thr && kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 4>), gk, dim3(256), klds, s, P);
+  else if (!P.drop_thr && kocc == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 3>), gk, dim3(256), klds, s, P);
+  else if (!P.drop_thr && kocc == 4) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 4>), gk, dim3(256), klds, s, P);
+  else
+#endif
+  if (P.drop_thr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, 2>), gk, dim3(256), klds, s, P);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, 2>), gk, dim3(256), klds, s, P);
   return tmi_check_launch("tmi_attn_bwd(dkv)");
 }

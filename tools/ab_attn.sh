@@ -1,3 +1,4 @@
+# (the occupancy switches TMI_ATTN_FWD_OCC / _DQ_OCC / _DKV_OCC exist in `make EXPERIMENTS=1` builds only; the shipped library ignores them)
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "flash" > gpurun_out/t_flash.log 2>&1 || { tail -30 gpurun_out/t_flash.log; exit 1; }
 tail -1 gpurun_out/t_flash.log
