@@ -262,8 +262,9 @@ typedef struct tmi_attn_desc {
    * launch: the lone 100-row query tile is otherwise one latency chain of 24 key tiles on 96 of 256 CUs. */
   void* workspace;
   int64_t workspace_bytes;
-  /* tmi_attn_bwd only.  0 or 3: both passes; 1: the dQ pass alone (it also fills `delta`); 2: the dK/dV pass alone, after a
-   * dQ pass of the same descriptor has filled `delta`.  Lets a caller put the dK/dV pass of a cross-attention - whose results
+  /* tmi_attn_bwd only.  0 or 3: both passes (ONE launch when Tq <= 256 and Tk <= 256 - the dK/dV workgroups then compute the
+   * row sums themselves, in the dQ pass's order: the outputs and `delta` are bit for bit those of the two launches); 1: the dQ
+   * pass alone (it also fills `delta`); 2: the dK/dV pass alone, after a dQ pass of the same descriptor has filled `delta`.  Lets a caller put the dK/dV pass of a cross-attention - whose results
    * nothing on the decoder's backward chain waits for (W:255-301: dK, dV feed the shared k/v projections) - on another stream. */
   int32_t bwd_passes;
 } tmi_attn_desc;
